@@ -1,0 +1,244 @@
+"""SymPy -> DAG lowering and forward-mode differentiation on the DAG.
+
+Replaces, for the HIP backend, the reference's ``sm.cse`` + C printing
+(``opty/utils.py:745-757``) and its symbolic ``_forward_jacobian``
+(``opty/utils.py:82-228``): the structural sharing comes from hash-consing in
+:class:`opty_amd.codegen.ir.DAG`, the Jacobian from a sparse forward sweep that
+carries, for every DAG node, a ``{wrt-column: derivative node}`` dictionary.
+"""
+
+import sympy as sm
+
+from . import ir
+
+
+class LoweringError(NotImplementedError):
+    pass
+
+
+_UNARY_FUNCS = {
+    sm.sin: 'sin', sm.cos: 'cos', sm.tan: 'tan', sm.exp: 'exp',
+    sm.log: 'log', sm.Abs: 'abs', sm.sign: 'sign', sm.asin: 'asin',
+    sm.acos: 'acos', sm.atan: 'atan', sm.sinh: 'sinh', sm.cosh: 'cosh',
+    sm.tanh: 'tanh',
+}
+
+
+class Lowerer(object):
+    """Lowers SymPy expressions over a fixed symbol table into one DAG."""
+
+    def __init__(self, dag, symbol_nodes):
+        self.dag = dag
+        self.sym = dict(symbol_nodes)     # sympy Symbol -> node id
+        self._memo = {}
+
+    def lower(self, expr):
+        expr = sm.sympify(expr)
+        # explicit stack: (expr, visited) post-order, memoised on the SymPy
+        # expression so shared sub-trees are lowered once.
+        memo = self._memo
+        stack = [(expr, False)]
+        while stack:
+            e, ready = stack.pop()
+            if e in memo:
+                continue
+            if not ready and e.args and not e.is_Number:
+                stack.append((e, True))
+                for a in e.args:
+                    if a not in memo:
+                        stack.append((a, False))
+                continue
+            memo[e] = self._convert(e)
+        return memo[expr]
+
+    def _convert(self, e):
+        d = self.dag
+        m = self._memo
+        if e.is_Symbol:
+            try:
+                return self.sym[e]
+            except KeyError:
+                raise LoweringError('symbol %s is not an argument of the '
+                                    'discretised equations' % e)
+        if e.is_Number or isinstance(e, sm.NumberSymbol):
+            return d.const(float(e))
+        if e.is_Add:
+            terms = [m[a] for a in e.args]
+            # node-invariant terms first so that they pair up with each other
+            terms.sort(key=lambda i: (not d.uni[i],))
+            return d.sum(terms)
+        if e.is_Mul:
+            num_u, num_v, den = [], [], []
+            for a in e.args:
+                if a.is_Pow and a.exp.is_Number and a.exp.is_negative:
+                    den.append(m[a.base] if a.exp == -1 else
+                               self._pow(m[a.base], -a.exp))
+                else:
+                    (num_u if d.uni[m[a]] else num_v).append(m[a])
+            num = d.mul(d.prod(num_u), d.prod(num_v)) if num_u else \
+                d.prod(num_v)
+            if den:
+                den.sort(key=lambda i: (not d.uni[i],))
+                return d.div(num, d.prod(den))
+            return num
+        if e.is_Pow:
+            return self._pow(m[e.base], e.exp, m.get(e.exp))
+        f = e.func
+        if f in _UNARY_FUNCS:
+            return d.unary(_UNARY_FUNCS[f], m[e.args[0]])
+        if f is sm.atan2:
+            return d.binary(ir.ATAN2, m[e.args[0]], m[e.args[1]])
+        if f in (sm.Max, sm.Min):
+            name = ir.MAX if f is sm.Max else ir.MIN
+            acc = m[e.args[0]]
+            for a in e.args[1:]:
+                acc = d.binary(name, acc, m[a])
+            return acc
+        if f is sm.Heaviside:
+            return d.unary('step', m[e.args[0]])
+        raise LoweringError('cannot lower %s (%s) to the HIP backend'
+                            % (f, e))
+
+    def _pow(self, base, exp, exp_node=None):
+        d = self.dag
+        exp = sm.sympify(exp)
+        if exp.is_Integer:
+            return d.powi(base, int(exp))
+        if exp.is_Number:
+            return d.pow(base, d.const(float(exp)))
+        if exp_node is None:
+            exp_node = self.lower(exp)
+        return d.pow(base, exp_node)
+
+
+def forward_jacobian(dag, outputs, wrt_inputs):
+    """Sparse forward-mode Jacobian on the DAG.
+
+    ``outputs``: node ids of the M expressions; ``wrt_inputs``: node ids (INPUT
+    nodes) of the C differentiation variables in column order.  Returns an
+    ``M x C`` list of lists of node ids (``dag.zero`` for structural zeros).
+    """
+    d = dag
+    col_of = {node: k for k, node in enumerate(wrt_inputs)}
+    order = d.reachable(outputs)
+    grad = {}
+    zero = d.zero
+
+    def scaled(g, f):
+        return {k: d.mul(f, v) for k, v in g.items()}
+
+    def combine(ga, gb, sign=1):
+        if not gb:
+            return ga
+        out = dict(ga)
+        for k, v in gb.items():
+            if k in out:
+                out[k] = d.add(out[k], v) if sign > 0 else d.sub(out[k], v)
+            else:
+                out[k] = v if sign > 0 else d.neg(v)
+        return out
+
+    for i in order:
+        op = d.op[i]
+        if op == ir.CONST:
+            g = {}
+        elif op == ir.INPUT:
+            g = {col_of[i]: d.one} if i in col_of else {}
+        else:
+            a = d.args[i]
+            ga = grad[a[0]]
+            if op == ir.ADD:
+                g = combine(ga, grad[a[1]])
+            elif op == ir.SUB:
+                g = combine(ga, grad[a[1]], -1)
+            elif op == ir.NEG:
+                g = {k: d.neg(v) for k, v in ga.items()}
+            elif op == ir.MUL:
+                gb = grad[a[1]]
+                g = combine(scaled(ga, a[1]) if ga else {},
+                            scaled(gb, a[0]) if gb else {})
+            elif op == ir.DIV:
+                gb = grad[a[1]]
+                if not ga and not gb:
+                    g = {}
+                else:
+                    inv = d.div(d.one, a[1])
+                    g = scaled(ga, inv) if ga else {}
+                    if gb:
+                        # d(a/b) = da/b - (a/b) db / b
+                        g = combine(g, scaled(gb, d.mul(i, inv)), -1)
+            elif op == ir.POWI:
+                n = a[1]
+                g = scaled(ga, d.mul(d.const(n), d.powi(a[0], n - 1))) \
+                    if ga else {}
+            elif op == ir.POW:
+                gb = grad[a[1]]
+                g = {}
+                if ga:      # b * a**(b-1) da
+                    g = scaled(ga, d.mul(a[1], d.pow(
+                        a[0], d.sub(a[1], d.one))))
+                if gb:      # a**b log(a) db
+                    g = combine(g, scaled(gb, d.mul(i, d.unary('log',
+                                                              a[0]))))
+            elif op in (ir.MAX, ir.MIN):
+                gb = grad[a[1]]
+                if not ga and not gb:
+                    g = {}
+                else:
+                    diff = d.sub(a[0], a[1]) if op == ir.MAX else \
+                        d.sub(a[1], a[0])
+                    wa = d.unary('step', diff)       # 1 where a selected
+                    wb = d.sub(d.one, wa)
+                    g = combine(scaled(ga, wa) if ga else {},
+                                scaled(gb, wb) if gb else {})
+            elif op == ir.ATAN2:
+                gb = grad[a[1]]
+                if not ga and not gb:
+                    g = {}
+                else:
+                    y, x = a
+                    den = d.add(d.mul(x, x), d.mul(y, y))
+                    g = combine(scaled(ga, d.div(x, den)) if ga else {},
+                                scaled(gb, d.div(y, den)) if gb else {}, -1)
+            elif not ga:
+                g = {}
+            else:
+                x = a[0]
+                if op == 'sin':
+                    f = d.unary('cos', x)
+                elif op == 'cos':
+                    f = d.neg(d.unary('sin', x))
+                elif op == 'tan':
+                    f = d.add(d.one, d.mul(i, i))
+                elif op == 'exp':
+                    f = i
+                elif op == 'log':
+                    f = d.div(d.one, x)
+                elif op == 'sqrt':
+                    f = d.div(d.const(0.5), i)
+                elif op == 'abs':
+                    f = d.unary('sign', x)
+                elif op in ('sign', 'step'):
+                    f = zero
+                elif op == 'asin':
+                    f = d.div(d.one, d.unary('sqrt', d.sub(d.one,
+                                                          d.mul(x, x))))
+                elif op == 'acos':
+                    f = d.neg(d.div(d.one, d.unary('sqrt', d.sub(
+                        d.one, d.mul(x, x)))))
+                elif op == 'atan':
+                    f = d.div(d.one, d.add(d.one, d.mul(x, x)))
+                elif op == 'sinh':
+                    f = d.unary('cosh', x)
+                elif op == 'cosh':
+                    f = d.unary('sinh', x)
+                elif op == 'tanh':
+                    f = d.sub(d.one, d.mul(i, i))
+                else:
+                    raise LoweringError('no derivative rule for %s' % op)
+                g = scaled(ga, f) if f != zero else {}
+        # drop structural zeros that simplification produced
+        grad[i] = {k: v for k, v in g.items() if v != zero}
+
+    ncol = len(wrt_inputs)
+    return [[grad[o].get(k, zero) for k in range(ncol)] for o in outputs]

@@ -1,0 +1,117 @@
+"""Builds the per-problem *collocation program*: one DAG holding the M
+discretised defect equations, their M x C analytic partials and the instance
+constraints, plus the tables that say where every DAG input lives in device
+memory.
+
+This is the HIP backend's counterpart of what the reference assembles inside
+``_gen_multi_arg_con_func`` / ``_gen_multi_arg_con_jac_func``
+(``opty/direct_collocation.py:2304-2380``, ``:2692-2805``): the argument list
+(``args``), the differentiation variables (``wrt``) and the expressions handed
+to ``ufuncify_matrix``.
+"""
+
+from . import ir
+from .lower import Lowerer, forward_jacobian
+
+
+class CollocationProgram(object):
+    """Plain data; consumed by :mod:`opty_amd.codegen.emit_hip`.
+
+    Attributes
+    ----------
+    dag : ir.DAG
+    con_out : list of M node ids (defect equations)
+    jac_out : list of M*C node ids, row-major ``[j*C + k]``
+    inst_con_out / inst_jac_out : node ids of the instance constraints and of
+        their partials (in the order of ``jacobian_indices``' tail)
+    rows : list, one entry per trajectory row ``('free', k)`` (row ``k`` of
+        the ``free`` vector viewed as ``(n+q, N)``) or ``('known', j)``
+    cur_offset / adj_offset : time-node offset of the current / adjacent
+        value relative to the constraint node (BE: 1/0, midpoint: 0/1)
+    pars : list, one entry per parameter ``('known', k)`` or ``('tail', j)``
+        (``free[(n+q)*N + j]``)
+    h : ``('fixed',)`` or ``('tail', r)``
+    """
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    @property
+    def P(self):
+        return self.M*self.C
+
+
+def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
+                  num_known_traj, parameters, num_known_par, h_sym,
+                  variable_duration, wrt, method, instance=None):
+    """Lowers the discretised equations and differentiates them.
+
+    Parameters mirror the reference's locals: ``state_cur``/``state_adj`` are
+    the ``xi`` and ``xp`` (backward Euler) or ``xn`` (midpoint) symbols,
+    ``traj_cur``/``traj_adj`` the ``si``/``sn`` symbols of *all* m input
+    trajectories (known first), ``parameters`` known-then-unknown, ``wrt`` the
+    column order of ``opty/direct_collocation.py:2719-2737``.
+
+    ``instance``: optional ``(expressions, atom_symbols, known_par_syms)`` --
+    instance constraints written over one placeholder Symbol per function
+    atom; lowered into the same DAG with INPUT kind ``'free'``.
+    """
+    dag = ir.DAG()
+    n = len(state_cur)
+    m = len(traj_cur)
+    q = m - num_known_traj
+    r = len(parameters) - num_known_par
+    table = {}
+    for k, s in enumerate(state_cur):
+        table[s] = dag.input('cur', k)
+    for k, s in enumerate(state_adj):
+        table[s] = dag.input('adj', k)
+    for k, s in enumerate(traj_cur):
+        table[s] = dag.input('cur', n + k)
+    if method == 'midpoint':
+        for k, s in enumerate(traj_adj):
+            table[s] = dag.input('adj', n + k)
+    for k, s in enumerate(parameters):
+        table[s] = dag.input('par', k)
+    table[h_sym] = dag.input('h', 0)
+
+    low = Lowerer(dag, table)
+    con_out = [low.lower(e) for e in discrete_eom]
+    wrt_nodes = [table[s] for s in wrt]
+    jac = forward_jacobian(dag, con_out, wrt_nodes)
+    jac_out = [node for row in jac for node in row]
+
+    # row r of the slab: states then unknown inputs come from `free`
+    # (``free`` viewed as (n+q, N), opty/utils.py:308-318); known inputs from
+    # the known-trajectory buffer.  input_trajectories = known + unknown.
+    rows = [('free', k) for k in range(n)]
+    rows += [('known', j) for j in range(num_known_traj)]
+    rows += [('free', n + j) for j in range(q)]
+    pars = [('known', k) for k in range(num_known_par)]
+    pars += [('tail', j) for j in range(r)]
+    h = ('tail', r) if variable_duration else ('fixed',)
+
+    inst_con_out, inst_jac_out, num_atoms = [], [], 0
+    if instance is not None:
+        exprs, atom_syms, grads = instance
+        itable = {s: dag.input('free', a) for a, s in enumerate(atom_syms)}
+        for k, s in enumerate(parameters[:num_known_par]):
+            itable[s] = dag.input('par', k)
+        ilow = Lowerer(dag, itable)
+        num_atoms = len(atom_syms)
+        for e, atoms in zip(exprs, grads):
+            node = ilow.lower(e)
+            inst_con_out.append(node)
+            if atoms:
+                g = forward_jacobian(dag, [node], [itable[s] for s in atoms])
+                inst_jac_out += g[0]
+
+    return CollocationProgram(
+        dag=dag, con_out=con_out, jac_out=jac_out, n=n, m=m, q=q, r=r,
+        s=int(variable_duration), M=len(con_out), C=len(wrt),
+        num_known_traj=num_known_traj, num_known_par=num_known_par,
+        rows=rows, pars=pars, h=h, method=method,
+        cur_offset=1 if method == 'backward euler' else 0,
+        adj_offset=0 if method == 'backward euler' else 1,
+        inst_con_out=inst_con_out, inst_jac_out=inst_jac_out,
+        num_inst_atoms=num_atoms)

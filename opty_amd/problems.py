@@ -1,0 +1,195 @@
+"""Problem zoo: the direct-collocation problems BASELINE.json's ``configs`` name.
+
+Each factory returns a plain ``dict`` of keyword arguments that both this
+package's :class:`opty_amd.ConstraintCollocator` and the reference's
+``opty.ConstraintCollocator`` (``opty/direct_collocation.py:1406-1411``) accept,
+so parity tests, the golden-vector generator and ``bench.py`` all build the very
+same symbolic problem.
+
+Sizes (N nodes, n states, M equations, q unknown inputs, r unknown parameters,
+s variable duration, o instance constraints) follow SURVEY.md section 8(d).
+"""
+
+import numpy as np
+import sympy as sm
+import sympy.physics.mechanics as me
+
+__all__ = ['vyasarayani', 'pendulum_swing_up', 'n_link_cart_pendulum',
+           'mass_spring_damper', 'variable_duration_pendulum', 'CONFIGS',
+           'make_free']
+
+
+def vyasarayani(num_nodes=51, duration=50.0, method='backward euler'):
+    """Config 1: single-pendulum parameter identification.
+
+    EoM from ``examples/vyasarayani2011.py:44-48`` (``y1' - y2``,
+    ``y2' + p sin(y1)``), shrunk to N=51 / backward Euler as BASELINE.json
+    config 1 asks.  ``p`` is an unknown parameter.
+    """
+    p, t = sm.symbols('p, t')
+    y1, y2 = [f(t) for f in sm.symbols('y1, y2', cls=sm.Function)]
+    y = sm.Matrix([y1, y2])
+    eom = y.diff(t) - sm.Matrix([y2, -p*sm.sin(y1)])
+    return dict(equations_of_motion=eom, state_symbols=(y1, y2),
+                num_collocation_nodes=num_nodes,
+                node_time_interval=duration/(num_nodes - 1),
+                time_symbol=t, integration_method=method)
+
+
+def pendulum_swing_up(num_nodes=10000, duration=10.0, method='midpoint'):
+    """Config 2: 1-link pendulum swing-up with four instance constraints.
+
+    EoM and instance constraints from
+    ``examples-gallery/beginner/plot_pendulum_swing_up_fixed_duration.py:43-84``.
+    """
+    I, m, g, d, t = sm.symbols('I, m, g, d, t')
+    theta, omega, T = sm.symbols('theta, omega, T', cls=sm.Function)
+    eom = sm.Matrix([theta(t).diff() - omega(t),
+                     I*omega(t).diff() + m*g*d*sm.sin(theta(t)) - T(t)])
+    instance_constraints = (theta(0.0), theta(duration) - np.pi,
+                            omega(0.0), omega(duration))
+    return dict(equations_of_motion=eom,
+                state_symbols=(theta(t), omega(t)),
+                num_collocation_nodes=num_nodes,
+                node_time_interval=duration/(num_nodes - 1),
+                known_parameter_map={I: 1.0, m: 1.0, g: 9.81, d: 1.0},
+                instance_constraints=instance_constraints,
+                time_symbol=t, integration_method=method)
+
+
+def n_link_cart_pendulum(num_links=10, num_nodes=100000, interval=0.01,
+                         method='backward euler', variable_duration=False,
+                         unknown_masses=0):
+    """Configs 3/4 (num_links=10) and the config-5 stand-in (num_links=24).
+
+    ``sympy.physics.mechanics.models.n_link_pendulum_on_cart`` is the same
+    constructor the reference's own test uses with n=3
+    (``opty/tests/test_direct_collocation.py:2044-2048``); EoM is
+    ``mass_matrix_full @ x' - forcing_full``.  Parameters: g=9.81,
+    ``l_k = 1 + 0.01 k``, ``m_k = 1 + 0.01 k``; the
+    cart force F(t) is the one unknown input trajectory.
+
+    ``unknown_masses`` leaves the last that many masses free (r > 0) and
+    ``variable_duration`` makes ``h`` a free Symbol (s = 1); both are used by
+    parity tests to exercise every column class of the Jacobian block.
+    """
+    from sympy.physics.mechanics.models import n_link_pendulum_on_cart
+    # The reference's collocator assigns ``me.dynamicsymbols._t`` globally
+    # (``opty/direct_collocation.py:1492``); restore SymPy's default so the
+    # model is built with one consistent time symbol.
+    me.dynamicsymbols._t = sm.Symbol('t')
+    kane = n_link_pendulum_on_cart(n=num_links, cart_force=True,
+                                   joint_torques=False)
+    states = kane.q.col_join(kane.u)
+    t = me.dynamicsymbols._t
+    eom = kane.mass_matrix_full @ states.diff(t) - kane.forcing_full
+    par_map = {}
+    params = sorted((s for s in eom.free_symbols if s != t),
+                    key=lambda s: (s.name[0], int(s.name[1:] or 0)))
+    masses = [s for s in params if s.name.startswith('m')]
+    free_masses = set(masses[len(masses) - unknown_masses:]) \
+        if unknown_masses else set()
+    for s in params:
+        if s in free_masses:
+            continue
+        if s.name == 'g':
+            par_map[s] = 9.81
+        else:
+            par_map[s] = 1.0 + 0.01*int(s.name[1:])
+    h = sm.Symbol('h', real=True) if variable_duration else interval
+    return dict(equations_of_motion=sm.Matrix(eom),
+                state_symbols=tuple(states),
+                num_collocation_nodes=num_nodes,
+                node_time_interval=h,
+                known_parameter_map=par_map,
+                time_symbol=t, integration_method=method)
+
+
+def mass_spring_damper(num_nodes=4, interval=2.0, method='backward euler'):
+    """The tiny fixture system of ``TestConstraintCollocator``
+    (``opty/tests/test_direct_collocation.py:658-700``): ``m v' + c v + k x - f``
+    with known trajectory ``f`` and unknown parameter ``k``."""
+    m, c, k, t = sm.symbols('m, c, k, t')
+    x, v, f = [s(t) for s in sm.symbols('x, v, f', cls=sm.Function)]
+    eom = sm.Matrix([x.diff() - v, m*v.diff() + c*v + k*x - f])
+    return dict(equations_of_motion=eom, state_symbols=(x, v),
+                num_collocation_nodes=num_nodes, node_time_interval=interval,
+                known_parameter_map={m: 1.0, c: 2.0},
+                known_trajectory_map={f: np.linspace(1.0, 4.0, num_nodes)},
+                time_symbol=t, integration_method=method)
+
+
+def variable_duration_pendulum(num_nodes=60, method='midpoint'):
+    """Variable-duration (s=1) pendulum with instance constraints given as
+    integer multiples of ``h`` (the pattern of
+    ``TestConstraintCollocatorVariableDuration``,
+    ``opty/tests/test_direct_collocation.py:1713-1760``)."""
+    m, g, d, h = sm.symbols('m, g, d, h', real=True)
+    t = sm.Symbol('t')
+    theta, omega, T = [s(t) for s in sm.symbols('theta, omega, T',
+                                                cls=sm.Function)]
+    eom = sm.Matrix([theta.diff() - omega,
+                     m*d**2*omega.diff() + m*g*d*sm.sin(theta) - T])
+    N = num_nodes
+    inst = (theta.func(0*h), theta.func((N - 1)*h) - sm.pi,
+            omega.func(0*h), omega.func((N - 1)*h))
+    return dict(equations_of_motion=eom, state_symbols=(theta, omega),
+                num_collocation_nodes=N, node_time_interval=h,
+                known_parameter_map={m: 1.0, g: 9.81},
+                instance_constraints=inst,
+                time_symbol=t, integration_method=method)
+
+
+# name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
+# the reference finish in seconds; parity fixtures are generated from them.
+CONFIGS = {
+    'config1_vyasarayani': (vyasarayani, {}),
+    'config2_pendulum': (pendulum_swing_up, {}),
+    'config2_pendulum_small': (pendulum_swing_up, {'num_nodes': 101}),
+    'config3_10link': (n_link_cart_pendulum, {}),
+    'config3_10link_small': (n_link_cart_pendulum, {'num_nodes': 41}),
+    'pend3_link_midpoint_small': (n_link_cart_pendulum,
+                                  {'num_links': 3, 'num_nodes': 37,
+                                   'method': 'midpoint', 'interval': 0.02}),
+    'pend2_link_vardur_unkmass_small': (
+        n_link_cart_pendulum, {'num_links': 2, 'num_nodes': 33,
+                               'variable_duration': True,
+                               'unknown_masses': 2}),
+    'msd_be_small': (mass_spring_damper, {'num_nodes': 23}),
+    'msd_mid_small': (mass_spring_damper, {'num_nodes': 23,
+                                           'method': 'midpoint'}),
+    'vardur_pendulum_small': (variable_duration_pendulum, {}),
+    'config5_standin_24link': (n_link_cart_pendulum,
+                               {'num_links': 24, 'num_nodes': 50000,
+                                'variable_duration': True}),
+}
+
+
+def build(name):
+    """Instantiates the keyword dict for a named config."""
+    factory, kwargs = CONFIGS[name]
+    return factory(**kwargs)
+
+
+def make_free(num_free, seed=0, variable_duration=False, interval=0.01):
+    """Deterministic synthetic ``free`` vector: dyadic rationals in [-1, 1).
+
+    An integer hash (no libm, no RNG library state) so that every machine and
+    both the reference and this package see bit-identical inputs (SURVEY.md
+    section 8(c)/(d)).  Values are k/2**20 with k from a 64-bit mix of the
+    index and ``seed``; if the problem has a variable duration the last entry
+    (h) is set to ``interval``.
+    """
+    idx = np.arange(num_free, dtype=np.uint64)
+    x = idx + np.uint64(0x9E3779B97F4A7C15)*np.uint64(seed + 1)
+    with np.errstate(over='ignore'):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    k = (x >> np.uint64(43)).astype(np.int64) - (1 << 20)   # 21 bits signed
+    free = k.astype(np.float64)/float(1 << 20)
+    if variable_duration:
+        free[-1] = interval
+    return free

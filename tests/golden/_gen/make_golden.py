@@ -1,0 +1,133 @@
+#!/usr/bin/env python
+"""Generates the golden vectors under ``tests/golden/`` by running the REAL
+reference (``/root/reference/opty``, compiled Cython + C path) in the build
+container.  Run from the repo root::
+
+    python tests/golden/_gen/make_golden.py [name ...]
+
+The reference cannot travel to the GPU box, so only its inputs/outputs are
+committed (as ``.npz`` data), together with this script.  ``cyipopt`` is absent
+here; ``stubs/cyipopt.py`` is a ten-line stand-in that lets
+``opty/direct_collocation.py:10`` import.
+
+For every problem in ``opty_amd.problems.CONFIGS`` that is listed below it
+stores: the symbol ordering the reference derived, sizes, the deterministic
+``free`` recipe (seed) and
+
+* small N: the full ``constraints(free)``, ``jacobian(free)`` and
+  ``jacobian_indices()`` arrays;
+* large N: a strided node sample of the con/jac blocks, per-equation /
+  per-entry sums (order-insensitive checksums) and the index arrays only at the
+  sampled nodes (the closed form is validated on the small cases).
+"""
+
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..', '..'))
+sys.path.insert(0, os.path.join(HERE, 'stubs'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, REPO)
+
+import numpy as np                                            # noqa: E402
+import sympy as sm                                            # noqa: E402
+from opty.direct_collocation import ConstraintCollocator     # noqa: E402
+from opty_amd import problems                                 # noqa: E402
+
+OUT = os.path.abspath(os.path.join(HERE, '..'))
+
+SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
+         'config3_10link_small', 'pend3_link_midpoint_small',
+         'pend2_link_vardur_unkmass_small', 'msd_be_small', 'msd_mid_small',
+         'vardur_pendulum_small']
+LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
+
+
+def sample_nodes(num_con_nodes, stride):
+    idx = set(range(0, num_con_nodes, stride))
+    idx |= {0, 1, num_con_nodes - 2, num_con_nodes - 1}
+    return np.array(sorted(idx), dtype=np.int64)
+
+
+def run(name):
+    kw = problems.build(name)
+    t0 = time.time()
+    col = ConstraintCollocator(parallel=True, **kw)
+    con = col.generate_constraint_function()
+    jac = col.generate_jacobian_function()
+    rows, cols = col.jacobian_indices()
+    N = col.num_collocation_nodes
+    M = col.num_eom
+    vd = col._variable_duration
+    seed = 0
+    free = problems.make_free(col.num_free, seed=seed, variable_duration=vd,
+                              interval=0.01)
+    cv = con(free).copy()
+    jv = jac(free).copy()
+    o = col.num_instance_constraints
+    qn = col.num_unknown_input_trajectories
+    C = (2*col.num_states + (1 if col.integration_method ==
+                             'backward euler' else 2)*qn +
+         col.num_unknown_parameters + int(vd))
+    assert (len(jv) - (len(rows) - (N - 1)*M*C)) == (N - 1)*M*C
+    meta = dict(
+        name=name, N=N, M=M, n=col.num_states,
+        q=col.num_unknown_input_trajectories,
+        r=col.num_unknown_parameters, s=int(vd), o=o, C=int(C),
+        num_free=col.num_free, num_constraints=col.num_constraints,
+        nnz=len(rows), nnz_inst=int(len(rows) - (N - 1)*M*C),
+        method=col.integration_method, seed=seed,
+        states=[str(x) for x in col.state_symbols],
+        known_parameters=[str(x) for x in col.known_parameters],
+        unknown_parameters=[str(x) for x in col.unknown_parameters],
+        known_trajectories=[str(x) for x in col.known_input_trajectories],
+        unknown_trajectories=[str(x) for x in
+                              col.unknown_input_trajectories],
+        sympy=sm.__version__, numpy=np.__version__,
+        reference='csu-hmc/opty v1.6.0.dev0 (compiled cython backend, '
+                  'parallel=True)',
+        wall_s=round(time.time() - t0, 1))
+    assert rows.dtype == np.int64 and cols.dtype == np.int64
+    P = M*C
+    arrays = {}
+    if name in LARGE:
+        nodes = sample_nodes(N - 1, LARGE[name])
+        blk = jv[:P*(N - 1)].reshape(N - 1, P)
+        cb = cv[:M*(N - 1)].reshape(M, N - 1)
+        arrays.update(
+            nodes=nodes, jac_nodes=blk[nodes], con_nodes=cb[:, nodes],
+            rows_nodes=rows[:P*(N - 1)].reshape(N - 1, P)[nodes],
+            cols_nodes=cols[:P*(N - 1)].reshape(N - 1, P)[nodes],
+            jac_entry_sums=blk.sum(axis=0), con_eq_sums=cb.sum(axis=1),
+            jac_abs_sum=np.array([np.abs(blk).sum()]),
+            con_tail=cv[M*(N - 1):], jac_tail=jv[P*(N - 1):],
+            rows_tail=rows[P*(N - 1):], cols_tail=cols[P*(N - 1):])
+        meta['kind'] = 'sampled'
+    else:
+        arrays.update(free=free, con=cv, jac=jv, rows=rows, cols=cols)
+        meta['kind'] = 'full'
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    return meta
+
+
+def main():
+    names = sys.argv[1:] or (SMALL + list(LARGE))
+    manifest_path = os.path.join(OUT, 'MANIFEST.json')
+    manifest = {}
+    if os.path.exists(manifest_path):
+        with open(manifest_path) as f:
+            manifest = json.load(f)
+    for name in names:
+        meta = run(name)
+        manifest[name] = meta
+        print(name, {k: meta[k] for k in ('N', 'M', 'n', 'q', 'r', 's', 'o',
+                                          'C', 'nnz', 'wall_s')})
+        with open(manifest_path, 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+
+
+if __name__ == '__main__':
+    main()
