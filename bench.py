@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: constraint + Jacobian evaluations per second of
+the 10-link pendulum on a cart at N = 100 000 collocation nodes (BASELINE.json
+metric, ``configs[2]``), inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one ``constraints(free)`` + one ``jacobian(free)`` on a free
+vector that differs from the previous step's (rotating set of synthetic
+vectors already in HBM), evaluated through the C ABI (``libopty_hip.so``) with
+device pointers on torch's current stream.
+
+Multi-GPU (``--gpus N`` under ``torch.distributed.run``): the collocation
+nodes are sharded, one contiguous node range per rank with a one-node halo
+(SURVEY.md 8(e)); every rank owns 100 000 nodes of an N x 100 000-node problem
+(weak scaling) and leaves its slice of the outputs in its own HBM -- there is
+no data-path collective.  ``--gather`` adds the RCCL all-gather that
+reassembles the full constraint/Jacobian vectors (reported separately in
+``config``).
+
+Prints ONE JSON line (rank 0).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np                                             # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+WORKLOAD = 'config3_10link'
+
+
+def cpu_baseline(kw, budget_s=12.0):
+    """The oracle's C/OpenMP restatement of the reference's generated code,
+    timed on this box's host cores on a bounded number of repetitions of the
+    same N = 100 000 workload."""
+    from oracle.collocation_oracle import OracleCollocator
+    from opty_amd import problems
+    threads = os.cpu_count() or 1
+    orc = OracleCollocator(name='config3_10link', parallel=True, **kw)
+    con = orc.generate_constraint_function()
+    jac = orc.generate_jacobian_function()
+    frees = [problems.make_free(orc.num_free, seed=s) for s in range(3)]
+    con(frees[0]), jac(frees[0])                   # warm-up / page-in
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        f = frees[reps % 3]
+        con(f)
+        jac(f)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 200:
+            break
+    return dict(value=reps/el, unit='evals/s', cores=threads, kind='port',
+                sample='%d constraint+Jacobian evaluations of the full '
+                       'N=100000 10-link problem, OpenMP over nodes '
+                       '(gcc -O2 -fopenmp), reference-shaped wrappers '
+                       '(fresh con array + transpose copy)' % reps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--nodes', type=int, default=100000)
+    ap.add_argument('--gather', action='store_true',
+                    help='all-gather the sharded outputs over RCCL each step')
+    ap.add_argument('--fused', action='store_true',
+                    help='use the single-launch con+jac kernel')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from opty_amd import problems, hip_backend as hb
+    import opty_amd
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, 'launch with torch.distributed.run'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(
+            'cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    factory, fkw = problems.CONFIGS[WORKLOAD]
+    fkw = dict(fkw, num_nodes=args.nodes)
+    kw = factory(**fkw)
+    # every rank evaluates its own 100 000-node shard (nodes rank*N .. +N,
+    # with its one-node halo, is exactly an N-node collocation problem)
+    col = opty_amd.ConstraintCollocator(device=local_rank, **kw)
+    hip = col.hip
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    nfree, ncon, nnz = col.num_free, col.num_constraints, hip.nnz
+    frees = [torch.from_numpy(problems.make_free(nfree, seed=1000*rank + s))
+             .to(dev) for s in range(4)]
+    con = torch.empty(ncon, dtype=torch.float64, device=dev)
+    jac = torch.empty(nnz, dtype=torch.float64, device=dev)
+    gathered = None
+    if args.gather and world > 1:
+        gathered = (torch.empty(world*ncon, dtype=torch.float64, device=dev),
+                    torch.empty(world*nnz, dtype=torch.float64, device=dev))
+
+    def step(k):
+        f = frees[k % len(frees)]
+        if args.fused:
+            hip.eval_con_jac(f, con, jac, hb.DEVICE)
+        else:
+            hip.eval_con(f, con, hb.DEVICE)
+            hip.eval_jac(f, jac, hb.DEVICE)
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered[0], con)
+            dist.all_gather_into_tensor(gathered[1], jac)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # Dominant kernel (opty_jac) duration, measured live with HIP events on
+    # the stream the kernels are launched on.
+    barrier()
+    jac_ms = hip.time_eval(hb.EVAL_JAC, frees[0], None, jac, args.steps)
+    con_ms = hip.time_eval(hb.EVAL_CON, frees[1], con, None, args.steps)
+    fused_ms = hip.time_eval(hb.EVAL_FUSED, frees[2], con, jac, args.steps)
+    barrier()
+
+    if rank == 0:
+        prog = col._build_program()
+        P, M, N = prog.P, prog.M, args.nodes
+        # algorithmic bytes of one Jacobian launch: read
+        # `free` once, write the dense blocks once
+        jac_bytes = 8.0*nfree + 8.0*P*(N - 1)
+        con_bytes = 8.0*nfree + 8.0*M*(N - 1)
+        achieved = jac_bytes/(jac_ms*1e-3)/1e9
+        value = args.steps*world/elapsed
+        out = {
+            'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
+                      '(10-link pendulum on cart, backward Euler)',
+            'value': value, 'unit': 'evals/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3*elapsed/args.steps,
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': '10-link inverted pendulum on cart, %d nodes per '
+                            'GPU, backward Euler, n=M=22, q=1, C=45, nnz=%d '
+                            'per GPU' % (N, nnz),
+                'step': ('fused con+jac launch' if args.fused else
+                         'constraints(free) launch + jacobian(free) launch'),
+                'sharding': 'nodes sharded one contiguous range per GPU, '
+                            'outputs left distributed' +
+                            (', + RCCL all-gather of con and jac'
+                             if gathered is not None else ''),
+                'jac_groups': hip.desc['jac_groups'],
+                'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
+                'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
+                              'opty_conjac': fused_ms},
+                'pair_algorithmic_GB': (jac_bytes + con_bytes)/1e9,
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': 'opty_jac', 'achieved': achieved,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved/HBM_PEAK_GBS, 'traffic': None},
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(kw)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

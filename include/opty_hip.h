@@ -1,0 +1,135 @@
+/* opty_hip.h -- C ABI of libopty_hip.so, the MI355X-native replacement for the
+ * native code opty generates at run time for its direct-collocation hot path.
+ *
+ * What it replaces in the reference (csu-hmc/opty, paths relative to the
+ * reference root):
+ *
+ *   - the generated per-node C function  `void eval_matrix(double matrix[R*C],
+ *     double a0, ...)` (template opty/utils.py:483-498) and its Cython node
+ *     loop `eval_matrix_loop` (opty/utils.py:500-529), instantiated twice per
+ *     problem by ConstraintCollocator._gen_multi_arg_con_func
+ *     (opty/direct_collocation.py:2373-2378) and _gen_multi_arg_con_jac_func
+ *     (opty/direct_collocation.py:2798-2803);
+ *   - the free-vector unpacking and output re-layout around them
+ *     (opty/direct_collocation.py:2382-2446, :2816-2887, :2928-3001), which is
+ *     folded into the kernels: the library consumes `free` and produces the
+ *     flat `constraints(free)` / `jacobian(free)` vectors directly;
+ *   - ConstraintCollocator.jacobian_indices
+ *     (opty/direct_collocation.py:2450-2690).
+ *
+ * The per-problem device code is a gfx950 code object (.hsaco) produced by
+ * opty_amd.codegen (the counterpart of ufuncify_matrix, opty/utils.py:639-928)
+ * that exports the kernels `opty_con`, `opty_jac`, `opty_conjac`, `opty_uni`
+ * (node-invariant sub-expressions) and, when the problem has instance
+ * constraints, `opty_inst`.
+ *
+ * All functions return 0 on success and a non-zero code on failure;
+ * opty_hip_last_error() then holds a message (thread-local).  A handle is not
+ * thread-safe (neither is the reference: opty/utils.py:548, :672-675).  There
+ * is no CPU fallback: without a HIP device opty_hip_create fails.
+ *
+ * Layouts (identical to the reference's):
+ *   free : [x_0[0..N-1] ... x_{n-1}[..], u_0[0..N-1] ... u_{q-1}[..],
+ *           p_0..p_{r-1}, h]                 (opty/direct_collocation.py:116-125)
+ *   con  : con[j*(N-1) + i] for equation j, constraint node i, then the o
+ *           instance constraints            (opty/direct_collocation.py:2446)
+ *   jac  : jac[i*P + j*C + k], P = M*C, then the instance partials
+ *                                           (opty/direct_collocation.py:2885-2887)
+ *   rows/cols : int64 COO indices of every jac entry, same order
+ *                                           (opty/direct_collocation.py:2628-2688)
+ */
+#ifndef OPTY_HIP_H
+#define OPTY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct opty_hip_problem opty_hip_problem;
+
+enum { OPTY_HIP_BACKWARD_EULER = 0, OPTY_HIP_MIDPOINT = 1 };
+/* where the caller's `free` / output buffers live */
+enum { OPTY_HIP_HOST = 0, OPTY_HIP_DEVICE = 1 };
+/* selector for opty_hip_time_eval */
+enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
+       OPTY_HIP_EVAL_FUSED = 3 };
+
+typedef struct opty_hip_desc {
+    int64_t N;            /* collocation (time) nodes                        */
+    int32_t n;            /* states                                          */
+    int32_t M;            /* equations of motion                             */
+    int32_t m_known;      /* known input trajectories                        */
+    int32_t q;            /* unknown input trajectories                      */
+    int32_t p_known;      /* known parameters                                */
+    int32_t r;            /* unknown parameters                              */
+    int32_t s;            /* 1 if the node time interval is free             */
+    int32_t C;            /* columns of the per-node block (len(wrt))        */
+    int32_t method;       /* OPTY_HIP_BACKWARD_EULER / OPTY_HIP_MIDPOINT     */
+    int32_t num_inst;     /* o: instance constraints                         */
+    int32_t nnz_inst;     /* instance-constraint Jacobian entries            */
+    int32_t num_inst_atoms; /* distinct x(t_k) atoms in instance constraints */
+    int32_t jac_groups;   /* waves per 64-node block of opty_jac/opty_conjac */
+    int32_t num_uniform;  /* entries of the node-invariant table (opty_uni)  */
+    int32_t uniform_dynamic; /* 1 if that table depends on `free` (r+s > 0)  */
+    int32_t device;       /* HIP device ordinal                              */
+} opty_hip_desc;
+
+/* Loads the code object and allocates the device-side state (known
+ * parameters, known trajectories, staging buffers). */
+int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
+                    opty_hip_problem **out);
+int opty_hip_destroy(opty_hip_problem *p);
+
+/* Use an existing hipStream_t (e.g. torch's current stream) for all work of
+ * this handle; NULL restores the handle's own stream. */
+int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream);
+int opty_hip_synchronize(opty_hip_problem *p);
+
+/* Values of the known parameters in ConstraintCollocator.known_parameters
+ * order (replaces the scalar by-value arguments c0.. of eval_matrix). */
+int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
+                                  int32_t count);
+/* Node time interval when it is not a free variable. */
+int opty_hip_set_interval(opty_hip_problem *p, double h);
+/* (m_known x N) row-major host array, known_input_trajectories order. */
+int opty_hip_set_known_trajectories(opty_hip_problem *p, const double *values,
+                                    int32_t mem);
+/* Instance constraints: free-vector index of every atom, and the COO
+ * rows/cols of the instance part of the Jacobian (host arrays). */
+int opty_hip_set_instance_indices(opty_hip_problem *p,
+                                  const int64_t *atom_free_index,
+                                  const int64_t *rows, const int64_t *cols);
+
+int64_t opty_hip_num_free(const opty_hip_problem *p);
+int64_t opty_hip_num_constraints(const opty_hip_problem *p);
+int64_t opty_hip_nnz(const opty_hip_problem *p);
+
+/* constraints(free): writes num_constraints doubles. */
+int opty_hip_eval_con(opty_hip_problem *p, const double *free, double *con,
+                      int32_t mem);
+/* jacobian(free): writes nnz doubles. */
+int opty_hip_eval_jac(opty_hip_problem *p, const double *free, double *jac,
+                      int32_t mem);
+/* both from one kernel launch (shared sub-expressions). */
+int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
+                          double *jac, int32_t mem);
+/* jacobian_indices(): writes nnz int64 rows and cols. */
+int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
+                              int64_t *cols, int32_t mem);
+
+/* Runs `iters` evaluations back to back on the handle's stream with device
+ * buffers and returns the mean milliseconds per evaluation measured with
+ * hipEvents recorded on that stream. */
+int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
+                       double *con, double *jac, int32_t iters,
+                       float *ms_per_iter);
+
+int opty_hip_device_count(void);
+const char *opty_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTY_HIP_H */

@@ -1,0 +1,9 @@
+"""opty_amd -- MI355X-native constraint and Jacobian evaluator for opty-style
+direct collocation (drop-in for ``opty.ConstraintCollocator`` / ``Problem``
+on the hot path)."""
+
+from .direct_collocation import ConstraintCollocator, Problem
+from .utils import parse_free
+
+__all__ = ['ConstraintCollocator', 'Problem', 'parse_free']
+__version__ = '0.1.0'

@@ -6,6 +6,12 @@ reference emits (``opty/utils.py:483-529``): instead of a scalar
 ``eval_matrix`` called from an OpenMP node loop it contains wave-per-64-nodes
 kernels built on ``csrc/opty_device.h``:
 
+``opty_uni``      one lane evaluates every *node-invariant* sub-expression
+                  (anything that depends on parameters / h only -- the
+                  reference recomputes those per node)
+                  into a small table ``uni[]`` that the other kernels read
+                  with scalar loads; it only has to run when parameters, h or
+                  (for unknown parameters / variable duration) ``free`` change
 ``opty_con``      constraints, equation-major coalesced stores
 ``opty_jac``      Jacobian blocks, staged through an LDS tile in chunks of
                   ``KC`` entries and flushed node-major with 16-byte stores;
@@ -16,9 +22,14 @@ kernels built on ``csrc/opty_device.h``:
 ``opty_conjac``   both outputs from one launch (shared sub-expressions)
 ``opty_inst``     instance-constraint values and partials (one lane)
 
-Scheduling: outputs are visited in memory order; each output's not-yet-emitted
-operands are emitted depth-first just before it, so temporaries are created as
-late as possible and LLVM's register allocator sees short live ranges.
+Register pressure is the hard part: a 10-link pendulum
+Jacobian has thousands of temporaries.  The printer therefore
+
+* keeps per-node *inputs* in an LDS slab for the whole kernel and re-reads
+  them per chunk instead of holding ~2n+m doubles in VGPRs,
+* re-loads node-invariant values per chunk through scalar loads (SGPRs),
+* visits outputs in memory order and emits each output's not-yet-available
+  operands depth-first right before it, so temporaries are born late.
 """
 
 import hashlib
@@ -28,16 +39,33 @@ from . import ir
 WAVE = 64
 TS = 65
 
+KERNEL_PARAMS = (
+    'const double *__restrict__ free_, const double *__restrict__ known_traj, '
+    'const double *__restrict__ params, const double *__restrict__ uni_c, '
+    'double *__restrict__ uni_w, const long long *__restrict__ inst_idx, '
+    'double *__restrict__ con, double *__restrict__ jac, double h, '
+    'long long N, long long con_stride, long long node_begin, '
+    'long long node_end')
+
 
 class EmitOptions(object):
-    def __init__(self, chunk=32, groups=None, lds_slab=True):
+    """Knobs of the printer.
+
+    chunk : entries of the per-node block staged per LDS tile flush (even)
+    groups : waves per 64-node block for the Jacobian kernels (None = auto)
+    max_live : auto-grouping target for the number of simultaneously live
+        float64 temporaries of one wave
+    """
+
+    def __init__(self, chunk=32, groups=None, max_live=100):
         self.chunk = int(chunk)
+        assert self.chunk % 2 == 0 and self.chunk >= 2
         self.groups = groups
-        self.lds_slab = bool(lds_slab)
+        self.max_live = int(max_live)
 
     def key(self):
-        return 'chunk=%d groups=%s slab=%d' % (self.chunk, self.groups,
-                                               self.lds_slab)
+        return 'chunk=%d groups=%s max_live=%d' % (self.chunk, self.groups,
+                                                   self.max_live)
 
 
 def _lit(v):
@@ -46,50 +74,75 @@ def _lit(v):
     if v in (float('inf'), float('-inf')):
         return ('-' if v < 0 else '') + '__builtin_inf()'
     s = repr(float(v))
-    if 'e' not in s and '.' not in s:
+    if 'e' not in s and '.' not in s and 'n' not in s:
         s += '.0'
     return s
 
 
 class _Body(object):
-    """Emits straight-line code for a set of DAG nodes, once each."""
+    """Emits straight-line code for DAG nodes.
 
-    def __init__(self, dag, needed, name_of_input):
+    ``leaf(i)`` decides whether node ``i`` is a *leaf* of this body -- a value
+    that is fetched (LDS / scalar load) rather than computed -- and returns
+    the C expression that fetches it, or None.  Leaves are re-fetched in every
+    scope (``new_scope``), computed temporaries are emitted once.
+    """
+
+    def __init__(self, dag, needed, leaf):
         self.dag = dag
         self.lines = []
         self.done = {}
-        self.needed = needed            # set of node ids reachable in scope
-        self.name_of_input = name_of_input
+        self.scope = {}
+        self.scope_id = 0
+        self.needed = needed
+        self.leaf = leaf
+
+    def new_scope(self):
+        self.scope = {}
+        self.scope_id += 1
 
     def ref(self, i):
         d = self.dag
         if d.op[i] == ir.CONST:
             v = d.value(i)
             return _lit(v) if v >= 0 else '(%s)' % _lit(v)
+        if i in self.scope:
+            return self.scope[i]
         return self.done[i]
 
+    def _have(self, i):
+        return i in self.done or i in self.scope or \
+            self.dag.op[i] == ir.CONST
+
+    def _fetch(self, i):
+        src = self.leaf(i)
+        if src is None:
+            return False
+        name = 'f%d_%d' % (i, self.scope_id)
+        self.lines.append('const double %s = %s;' % (name, src))
+        self.scope[i] = name
+        return True
+
     def emit(self, root):
-        """Makes sure ``root`` is computed; returns the C expression naming
+        """Makes sure ``root`` is available; returns the C expression naming
         it."""
         d = self.dag
-        if d.op[root] == ir.CONST:
-            return self.ref(root)
         stack = [(root, False)]
         while stack:
             i, ready = stack.pop()
-            if i in self.done or d.op[i] == ir.CONST:
-                continue
-            if d.op[i] == ir.INPUT:
-                self.done[i] = self.name_of_input(i)
+            if self._have(i):
                 continue
             if not ready:
+                if self.leaf(i) is not None:
+                    self._fetch(i)
+                    continue
                 stack.append((i, True))
                 for j in reversed(d.operands(i)):
-                    if j not in self.done and d.op[j] != ir.CONST:
+                    if not self._have(j):
                         stack.append((j, False))
                 continue
             self._emit_node(i)
-        return self.done[root]
+        return self.ref(root)
 
     def _emit_node(self, i):
         d = self.dag
@@ -126,7 +179,8 @@ class _Body(object):
         elif op in ('sin', 'cos'):
             other = 'cos' if op == 'sin' else 'sin'
             j = d._memo.get((other, a))
-            if j is not None and j in self.needed and j not in self.done:
+            if (j is not None and j in self.needed and not self._have(j)
+                    and self.leaf(j) is None):
                 s_id, c_id = (i, j) if op == 'sin' else (j, i)
                 self.lines.append('double v%d, v%d; sincos(%s, &v%d, &v%d);'
                                   % (s_id, c_id, r(a[0]), s_id, c_id))
@@ -149,124 +203,172 @@ class _Body(object):
         self.done[i] = name
 
 
-class _KernelWriter(object):
+def _max_live(dag, chunks, is_leaf):
+    """Largest number of simultaneously live computed temporaries when the
+    chunks' roots are emitted depth-first in order (what ``_Body`` does)."""
+    need = set()
+    stack = [r for c in chunks for r in c]
+    while stack:
+        i = stack.pop()
+        if i in need or dag.op[i] == ir.CONST or is_leaf(i):
+            continue
+        need.add(i)
+        stack.extend(dag.operands(i))
+    uses = dict.fromkeys(need, 0)
+    for i in need:
+        for j in set(dag.operands(i)):
+            if j in uses:
+                uses[j] += 1
+    for c in chunks:
+        for r in c:
+            if r in uses:
+                uses[r] += 1
+    done, live, peak = set(), 0, 0
+    for c in chunks:
+        for root in c:
+            if root not in uses:
+                continue
+            stack = [(root, False)]
+            while stack:
+                i, ready = stack.pop()
+                if i in done or i not in uses:
+                    continue
+                if not ready:
+                    stack.append((i, True))
+                    for j in reversed(dag.operands(i)):
+                        if j in uses and j not in done:
+                            stack.append((j, False))
+                    continue
+                done.add(i)
+                live += 1
+                peak = max(peak, live)
+                for j in set(dag.operands(i)):
+                    if j in uses:
+                        uses[j] -= 1
+                        if uses[j] == 0:
+                            live -= 1
+            uses[root] -= 1
+            if uses[root] == 0:
+                live -= 1
+    return peak
+
+
+class _ModuleWriter(object):
 
     def __init__(self, prog, opts):
         self.p = prog
         self.o = opts
         self.dag = prog.dag
+        self.uni_slot = {}          # uniform frontier node -> slot in uni[]
 
-    # -- input plumbing --------------------------------------------------------
-    def _input_name(self, i):
-        kind, idx = self.dag.args[i]
-        return {'cur': 'xc%d', 'adj': 'xa%d', 'par': 'p%d', 'h': 'hh',
-                'free': 'fa%d'}[kind] % ((idx,) if kind != 'h' else ())
+    # -- leaves -------------------------------------------------------------
+    def _is_vec_input(self, i):
+        return self.dag.op[i] == ir.INPUT and \
+            self.dag.args[i][0] in ('cur', 'adj')
+
+    def _uniform_leaf(self, i):
+        """Non-constant node-invariant node: lives in the ``uni`` table."""
+        return self.dag.uni[i] and self.dag.op[i] != ir.CONST
+
+    def _slot(self, i):
+        s = self.uni_slot.get(i)
+        if s is None:
+            s = self.uni_slot[i] = len(self.uni_slot)
+        return s
 
     def _row_ptr(self, r):
         src, k = self.p.rows[r]
         if src == 'free':
-            return 'a.free_ + %dLL*a.N' % k
-        return 'a.known_traj + %dLL*a.N' % k
+            return 'free_ + %dLL*N' % k
+        return 'known_traj + %dLL*N' % k
 
-    def _scalar_loads(self, inputs):
-        """Loads of the node-invariant inputs (uniform addresses)."""
+    def _scalar_source(self, i):
+        """C expression loading a node-invariant INPUT node from its home."""
         p = self.p
-        out = []
-        tail = 'a.free_[%dLL*a.N + %%d]' % (p.n + p.q)
-        for i in inputs:
-            kind, idx = self.dag.args[i]
-            if kind == 'par':
-                src, k = p.pars[idx]
-                e = ('a.params[%d]' % k) if src == 'known' else tail % k
-                out.append('const double p%d = %s;' % (idx, e))
-            elif kind == 'h':
-                e = 'a.h' if p.h[0] == 'fixed' else tail % p.h[1]
-                out.append('const double hh = %s;' % e)
-            elif kind == 'free':
-                out.append('const double fa%d = a.free_[a.inst_idx[%d]];'
-                           % (idx, idx))
-        return out
+        kind, idx = self.dag.args[i]
+        tail = 'free_[%dLL*N + %%d]' % (p.n + p.q)
+        if kind == 'par':
+            src, k = p.pars[idx]
+            return ('params[%d]' % k) if src == 'known' else tail % k
+        if kind == 'h':
+            return 'h' if p.h[0] == 'fixed' else tail % p.h[1]
+        if kind == 'free':
+            return 'free_[inst_idx[%d]]' % idx
+        raise AssertionError(kind)
 
-    def _vector_loads(self, inputs):
-        """Per-node inputs: LDS slab (one coalesced row load, both time
-        offsets read from LDS) or direct global loads."""
-        p = self.p
-        rows = sorted({self.dag.args[i][1] for i in inputs})
-        use = {}
-        for i in inputs:
-            kind, r = self.dag.args[i]
-            use.setdefault(r, set()).add(kind)
-        out = []
-        if not rows:
-            return out, 0
-        if self.o.lds_slab:
-            for s, r in enumerate(rows):
-                out.append('opty_slab_load(lds, %d, %s, node0, a.N - 1, lane);'
-                           % (s, self._row_ptr(r)))
-            out.append('opty_wave_sync();')
-            for s, r in enumerate(rows):
-                if 'cur' in use[r]:
-                    out.append('const double xc%d = lds[%d + lane + %d];'
-                               % (r, s*TS, p.cur_offset))
-                if 'adj' in use[r]:
-                    out.append('const double xa%d = lds[%d + lane + %d];'
-                               % (r, s*TS, p.adj_offset))
-            out.append('opty_wave_sync();')
-            return out, len(rows)
-        for r in rows:
-            if 'cur' in use[r]:
-                out.append('const double xc%d = (%s)[tn + %d];'
-                           % (r, self._row_ptr(r), p.cur_offset))
-            if 'adj' in use[r]:
-                out.append('const double xa%d = (%s)[tn + %d];'
-                           % (r, self._row_ptr(r), p.adj_offset))
-        return out, 0
+    # -- grouping --------------------------------------------------------------
+    def _chunks(self, e0, e1):
+        K = self.o.chunk
+        return [(c, min(c + K, e1)) for c in range(e0, e1, K)]
 
-    def _split_inputs(self, roots):
-        need = self.dag.reachable(roots)
-        vec, sca = [], []
-        for i in need:
-            if self.dag.op[i] == ir.INPUT:
-                (vec if self.dag.args[i][0] in ('cur', 'adj')
-                 else sca).append(i)
-        return set(need), vec, sca
-
-    # -- kernels ---------------------------------------------------------------
     def group_ranges(self):
         """Splits the P entries of the block into G contiguous ranges whose
-        boundaries are multiples of the chunk width (hence even)."""
+        boundaries are multiples of the chunk width (hence even).  With
+        ``groups=None`` the number of groups is the smallest for which every
+        group's estimated live temporaries stay below ``max_live``."""
         P, K = self.p.P, self.o.chunk
-        G = self.o.groups
         nchunks = (P + K - 1)//K
-        if G is None:
-            G = max(1, min(8, nchunks//8))
-        G = max(1, min(G, nchunks))
-        bounds = [((g*nchunks)//G)*K for g in range(G)] + [P]
-        return [(bounds[g], bounds[g + 1]) for g in range(G)]
 
+        def split(G):
+            b = [((g*nchunks)//G)*K for g in range(G)] + [P]
+            return [(b[g], b[g + 1]) for g in range(G)]
+
+        if self.o.groups is not None:
+            return split(max(1, min(int(self.o.groups), nchunks)))
+        leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
+        G = 1
+        while True:
+            ranges = split(G)
+            worst = max(
+                _max_live(self.dag,
+                          [self.p.jac_out[a:b] for a, b in self._chunks(*rg)],
+                          leaf)
+                for rg in ranges)
+            if worst <= self.o.max_live or G >= min(nchunks, 16):
+                return ranges
+            G += 1
+
+    # -- kernels ---------------------------------------------------------------
     def _group_body(self, e0, e1, con_rows):
         """Code for one wave evaluating Jacobian entries [e0, e1) and the
-        constraint rows ``con_rows`` of its 64 nodes."""
-        p = self.p
+        constraint rows ``con_rows`` of its 64 nodes.  Returns (lines, number
+        of slab rows)."""
+        p, d = self.p, self.dag
         K = self.o.chunk
         roots = [p.jac_out[e] for e in range(e0, e1)]
         roots += [p.con_out[j] for j in con_rows]
-        needed, vec, sca = self._split_inputs(roots)
-        loads, nslab = self._vector_loads(vec)
-        body = _Body(self.dag, needed, self._input_name)
-        lines = loads + self._scalar_loads(sca)
-        wide = (p.P % 2 == 0)
+        needed = set(d.reachable(roots))
+        rows = sorted({d.args[i][1] for i in needed if self._is_vec_input(i)})
+        slab_of = {r: s for s, r in enumerate(rows)}
+        tile_rows = min(K, e1 - e0) if e1 > e0 else 0
+        slab0 = tile_rows*TS
+
+        def leaf(i):
+            if self._is_vec_input(i):
+                kind, r = d.args[i]
+                off = p.cur_offset if kind == 'cur' else p.adj_offset
+                return 'lds[%d + lane + %d]' % (slab0 + slab_of[r]*TS, off)
+            if self._uniform_leaf(i):
+                return 'uni_c[%d]' % self._slot(i)
+            return None
+
+        lines = []
+        for r in rows:
+            lines.append('opty_slab_load(lds + %d, %d, %s, node0, N - 1, '
+                         'lane);' % (slab0, slab_of[r], self._row_ptr(r)))
+        if rows:
+            lines.append('opty_wave_sync();')
+        body = _Body(d, needed, leaf)
         for j in con_rows:
             ref = body.emit(p.con_out[j])
-            body.lines.append('if (valid) a.con[%dLL*a.con_stride + node] = '
-                              '%s;' % (j, ref))
-        c0 = e0
-        while c0 < e1:
-            c1 = min(c0 + K, e1)
+            body.lines.append('if (valid) con[%dLL*con_stride + node] = %s;'
+                              % (j, ref))
+        wide = (p.P % 2 == 0)
+        for c0, c1 in self._chunks(e0, e1):
+            body.new_scope()
             for e in range(c0, c1):
                 ref = body.emit(p.jac_out[e])
-                body.lines.append('lds[%d + lane] = %s;'
-                                  % ((e - c0)*TS, ref))
+                body.lines.append('lds[%d + lane] = %s;' % ((e - c0)*TS, ref))
             body.lines.append('opty_wave_sync();')
             w = c1 - c0
             fl = 'opty_flush16' if (wide and w % 2 == 0 and c0 % 2 == 0) \
@@ -274,27 +376,23 @@ class _KernelWriter(object):
             body.lines.append('%s<%d>(lds, jrow + %d, %dLL, nvalid, lane);'
                               % (fl, w, c0, p.P))
             body.lines.append('opty_wave_sync();')
-            c0 = c1
-        lines += body.lines
-        lds_rows = max(nslab, min(K, e1 - e0) if e1 > e0 else 0)
-        return lines, lds_rows
+        return lines + body.lines, tile_rows + len(rows)
 
     _PROLOGUE = '''\
     const int lane = threadIdx.x;
-    const long long nblk = (a.node_end - a.node_begin + 63)/64;
+    const long long nblk = (node_end - node_begin + 63)/64;
     {map}
     if (blk >= nblk) return;
-    const long long node0 = a.node_begin + blk*64;
+    const long long node0 = node_begin + blk*64;
     const long long node = node0 + lane;
-    const bool valid = node < a.node_end;
-    const long long rem = a.node_end - node0;
+    const bool valid = node < node_end;
+    const long long rem = node_end - node0;
     const int nvalid = rem < 64 ? (int)rem : 64;
-    const long long tn = valid ? node : a.node_end - 1;
-    double *jrow = a.jac + (node0 - a.node_begin)*{P}LL;
-    (void)tn; (void)jrow; (void)nvalid;
+    double *jrow = jac + (node0 - node_begin)*{P}LL;
+    (void)valid; (void)jrow; (void)nvalid; (void)node;
 '''
 
-    def _kernel(self, name, groups, con_of_group):
+    def kernel(self, name, groups, con_of_group):
         """One kernel; ``groups`` = list of (e0, e1); ``con_of_group[g]`` =
         constraint rows stored by group g."""
         G = len(groups)
@@ -315,7 +413,7 @@ class _KernelWriter(object):
                        'const long long blk = (slot/%d)*8 + xcd; '
                        'const int grp = (int)(slot %% %d);' % (G, G))
         src = ['extern "C" __global__ void __launch_bounds__(64)',
-               '%s(const OptyKernelArgs a)' % name, '{',
+               '%s(%s)' % (name, KERNEL_PARAMS), '{',
                '    __shared__ double lds[%d];' % (lds_rows*TS),
                self._PROLOGUE.format(map=mapping, P=self.p.P)]
         if G == 1:
@@ -332,36 +430,64 @@ class _KernelWriter(object):
         return '\n'.join(src), dict(name=name, groups=G,
                                     lds_bytes=lds_rows*TS*8)
 
+    def uniform_kernel(self):
+        """Must be printed after every kernel that allocates ``uni`` slots."""
+        d = self.dag
+        slots = sorted(self.uni_slot.items(), key=lambda kv: kv[1])
+        roots = [i for i, _ in slots]
+        needed = set(d.reachable(roots))
+
+        def leaf(i):
+            if d.op[i] == ir.INPUT:
+                return self._scalar_source(i)
+            return None
+
+        body = _Body(d, needed, leaf)
+        for i, s in slots:
+            ref = body.emit(i)
+            body.lines.append('uni_w[%d] = %s;' % (s, ref))
+        src = ['extern "C" __global__ void __launch_bounds__(64)',
+               'opty_uni(%s)' % KERNEL_PARAMS, '{',
+               '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
+        src += ['    ' + ln for ln in body.lines] + ['}']
+        dynamic = any(d.op[i] == ir.INPUT and
+                      self._scalar_source(i).startswith('free_')
+                      for i in needed)
+        return '\n'.join(src), len(slots), dynamic
+
     def inst_kernel(self):
-        p = self.p
+        p, d = self.p, self.dag
         roots = list(p.inst_con_out) + list(p.inst_jac_out)
-        needed, vec, sca = self._split_inputs(roots)
-        assert not vec
-        body = _Body(self.dag, needed, self._input_name)
-        lines = self._scalar_loads(sca)
+        needed = set(d.reachable(roots))
+
+        def leaf(i):
+            if d.op[i] == ir.INPUT:
+                return self._scalar_source(i)
+            return None
+
+        body = _Body(d, needed, leaf)
         for k, node in enumerate(p.inst_con_out):
             ref = body.emit(node)
-            body.lines.append('if (a.con) a.con[%dLL*a.con_stride + %d] = %s;'
+            body.lines.append('if (con) con[%dLL*con_stride + %d] = %s;'
                               % (p.M, k, ref))
         for k, node in enumerate(p.inst_jac_out):
             ref = body.emit(node)
-            body.lines.append('if (a.jac) a.jac[(a.node_end - a.node_begin)*'
-                              '%dLL + %d] = %s;' % (p.P, k, ref))
-        lines += body.lines
+            body.lines.append('if (jac) jac[(node_end - node_begin)*%dLL + '
+                              '%d] = %s;' % (p.P, k, ref))
         src = ['extern "C" __global__ void __launch_bounds__(64)',
-               'opty_inst(const OptyKernelArgs a)', '{',
+               'opty_inst(%s)' % KERNEL_PARAMS, '{',
                '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
-        src += ['    ' + ln for ln in lines] + ['}']
+        src += ['    ' + ln for ln in body.lines] + ['}']
         return '\n'.join(src), dict(name='opty_inst', groups=1, lds_bytes=0)
 
 
 def emit_module(prog, opts=None):
-    """Returns ``(source, meta)``; ``meta['kernels']`` describes the launch
-    geometry the runtime needs (kernel name, waves per node block)."""
+    """Returns ``(source, meta)``; ``meta`` describes the launch geometry the
+    runtime needs (waves per node block, size of the ``uni`` table, whether
+    the table depends on ``free``)."""
     opts = opts or EmitOptions()
-    w = _KernelWriter(prog, opts)
+    w = _ModuleWriter(prog, opts)
     groups = w.group_ranges()
-    G = len(groups)
     all_rows = list(range(prog.M))
     # constraint row j is stored by the wave that owns Jacobian row j's first
     # entry (their temporaries overlap the most)
@@ -371,25 +497,27 @@ def emit_module(prog, opts=None):
         for g, (e0, e1) in enumerate(groups):
             if e0 <= e < e1:
                 con_of[g].append(j)
-    parts = ['// generated by opty_amd.codegen.emit_hip -- do not edit',
-             '// %s' % opts.key(),
-             '#include "opty_device.h"', '']
+    parts = []
     kernels = {}
-    src, meta = w._kernel('opty_con', [(0, 0)], [all_rows])
-    parts += [src, '']
-    kernels['con'] = meta
-    src, meta = w._kernel('opty_jac', groups, [[] for _ in groups])
-    parts += [src, '']
-    kernels['jac'] = meta
-    src, meta = w._kernel('opty_conjac', groups, con_of)
-    parts += [src, '']
-    kernels['conjac'] = meta
+    for key, name, grp, cons in (
+            ('con', 'opty_con', [(0, 0)], [all_rows]),
+            ('jac', 'opty_jac', groups, [[] for _ in groups]),
+            ('conjac', 'opty_conjac', groups, con_of)):
+        src, meta = w.kernel(name, grp, cons)
+        parts += [src, '']
+        kernels[key] = meta
     if prog.inst_con_out:
         src, meta = w.inst_kernel()
         parts += [src, '']
         kernels['inst'] = meta
-    source = '\n'.join(parts)
+    src, num_uniform, dynamic = w.uniform_kernel()
+    parts += [src, '']
+    head = ['// generated by opty_amd.codegen.emit_hip -- do not edit',
+            '// %s' % opts.key(),
+            '#include "opty_device.h"', '']
+    source = '\n'.join(head + parts)
     meta = dict(kernels=kernels, groups=[list(g) for g in groups],
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
+                num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
                 sha=hashlib.sha256(source.encode()).hexdigest())
     return source, meta

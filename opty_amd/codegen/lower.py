@@ -78,8 +78,14 @@ class Lowerer(object):
             num = d.mul(d.prod(num_u), d.prod(num_v)) if num_u else \
                 d.prod(num_v)
             if den:
-                den.sort(key=lambda i: (not d.uni[i],))
-                return d.div(num, d.prod(den))
+                # a node-invariant denominator (typically h) becomes one
+                # shared reciprocal and a multiplication: x/h -> x*(1/h)
+                den_u = [i for i in den if d.uni[i]]
+                den_v = [i for i in den if not d.uni[i]]
+                if den_u:
+                    num = d.mul(d.div(d.one, d.prod(den_u)), num)
+                if den_v:
+                    num = d.div(num, d.prod(den_v))
             return num
         if e.is_Pow:
             return self._pow(m[e.base], e.exp, m.get(e.exp))

@@ -25,20 +25,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// ---- kernel argument block (mirrored in opty_hip.cpp: struct KernelArgs) ----
-struct OptyKernelArgs {
-    const double *free_;       // (n+q)*N + r + s free variables
-    const double *known_traj;  // m_known x N known input trajectories
-    const double *params;      // known parameter values
-    const long long *inst_idx; // free index of every instance-function atom
-    double *con;               // constraint output
-    double *jac;               // Jacobian value output
-    double h;                  // node time interval when it is not free
-    long long N;               // number of collocation (time) nodes
-    long long con_stride;      // distance between two equations in `con`
-    long long node_begin;      // first constraint node this launch evaluates
-    long long node_end;        // one past the last constraint node
-};
+// Every generated kernel takes the same argument list (mirrored by
+// `struct KernelArgs` in opty_hip.cpp, which is passed as the packed kernarg
+// buffer):
+//   const double *free_       (n+q)*N + r + s free variables
+//   const double *known_traj  m_known x N known input trajectories
+//   const double *params      known parameter values
+//   const double *uni_c       node-invariant table (read side)
+//   double       *uni_w       the same table (written by opty_uni only)
+//   const long long *inst_idx free index of every instance-function atom
+//   double *con, *jac         outputs
+//   double h                  node time interval when it is not free
+//   long long N               number of collocation (time) nodes
+//   long long con_stride      distance between two equations in `con`
+//   long long node_begin/end  constraint-node range this launch evaluates
 
 #define OPTY_WAVE 64
 // LDS row stride (in doubles) of both the input slab and the output tile.

@@ -1,0 +1,523 @@
+// opty_hip.cpp -- runtime behind include/opty_hip.h (libopty_hip.so).
+//
+// Owns, per problem handle: the loaded gfx950 code object with the generated
+// collocation kernels, the device copies of the node-invariant data (known
+// parameters, known trajectories, instance index tables), staging buffers for
+// callers that hand over host memory, and one HIP stream.  Evaluations are
+// plain kernel launches on that stream; nothing here computes on the CPU.
+//
+// Reference counterparts: the closures `constraints` / `constraints_jacobian`
+// (opty/direct_collocation.py:2382-2446, :2816-2887), the wrapper of
+// _wrap_constraint_funcs (:2928-3001) and jacobian_indices (:2450-2690).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/opty_hip.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                         \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess)                                                 \
+            return fail("%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+// The packed kernarg buffer; must match the parameter list every generated
+// kernel has (KERNEL_PARAMS in opty_amd/codegen/emit_hip.py).
+struct KernelArgs {
+    const double *free_;
+    const double *known_traj;
+    const double *params;
+    const double *uni_c;
+    double *uni_w;
+    const long long *inst_idx;
+    double *con;
+    double *jac;
+    double h;
+    long long N;
+    long long con_stride;
+    long long node_begin;
+    long long node_end;
+};
+
+// ---------------------------------------------------------------------------
+// jacobian_indices as a closed form; one lane per entry
+// pair, 16-byte stores.  Integer, HBM-write bound: 16 bytes per entry.
+// ---------------------------------------------------------------------------
+struct IndexDims {
+    long long N;      // time nodes
+    long long ncon;   // N - 1
+    int n, q, M, C, tail, method;
+};
+
+__device__ __forceinline__ void index_of(const IndexDims &d, long long i,
+                                         int j, int k, long long &row,
+                                         long long &col) {
+    row = (long long)j*d.ncon + i;
+    const int n = d.n, q = d.q;
+    const long long N = d.N;
+    if (d.method == OPTY_HIP_BACKWARD_EULER) {
+        if (k < n)              col = (long long)k*N + i + 1;
+        else if (k < 2*n)       col = (long long)(k - n)*N + i;
+        else if (k < 2*n + q)   col = (long long)(n + k - 2*n)*N + i + 1;
+        else                    col = (long long)(n + q)*N + (k - 2*n - q);
+    } else {
+        if (k < n)              col = (long long)k*N + i;
+        else if (k < 2*n)       col = (long long)(k - n)*N + i + 1;
+        else if (k < 2*n + q)   col = (long long)(n + k - 2*n)*N + i;
+        else if (k < 2*n + 2*q) col = (long long)(n + k - 2*n - q)*N + i + 1;
+        else                    col = (long long)(n + q)*N + (k - 2*n - 2*q);
+    }
+}
+
+// grid.x covers the nodes in blocks of `nodes_per_block`; the threads of a
+// block sweep the P entries of each of its nodes, so consecutive lanes write
+// consecutive int64s.
+__global__ void __launch_bounds__(256)
+opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
+                    int nodes_per_block) {
+    const int P = d.M*d.C;
+    const long long i0 = (long long)blockIdx.x*nodes_per_block;
+    for (int s = 0; s < nodes_per_block; ++s) {
+        const long long i = i0 + s;
+        if (i >= d.ncon) return;
+        long long *r = rows + i*P;
+        long long *c = cols + i*P;
+        for (int e = threadIdx.x; e < P; e += blockDim.x) {
+            const int j = e/d.C;
+            const int k = e - j*d.C;
+            long long row, col;
+            index_of(d, i, j, k, row, col);
+            r[e] = row;
+            c[e] = col;
+        }
+    }
+}
+
+}  // namespace
+
+struct opty_hip_problem {
+    opty_hip_desc d{};
+    hipModule_t module = nullptr;
+    hipFunction_t k_con = nullptr, k_jac = nullptr, k_conjac = nullptr,
+                  k_inst = nullptr, k_uni = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *d_params = nullptr, *d_known = nullptr, *d_uni = nullptr;
+    bool uni_dirty = true;   // node-invariant table needs (re)computing
+    long long *d_inst_idx = nullptr, *d_inst_rows = nullptr,
+              *d_inst_cols = nullptr;
+    double *d_free = nullptr, *d_con = nullptr, *d_jac = nullptr;  // staging
+    long long *d_rows = nullptr, *d_cols = nullptr;                // staging
+    double h = 0.0;
+    bool have_params = false, have_known = false, have_inst = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int64_t ncon_nodes() const { return d.N - 1; }
+    int64_t P() const { return (int64_t)d.M*d.C; }
+    int64_t num_free() const { return (int64_t)(d.n + d.q)*d.N + d.r + d.s; }
+    int64_t num_con() const { return (int64_t)d.M*ncon_nodes() + d.num_inst; }
+    int64_t nnz() const { return P()*ncon_nodes() + d.nnz_inst; }
+};
+
+namespace {
+
+int use_device(const opty_hip_problem *p) {
+    HIP_TRY(hipSetDevice(p->d.device));
+    return 0;
+}
+
+int check_ready(const opty_hip_problem *p) {
+    if (p->d.p_known > 0 && !p->have_params)
+        return fail("known parameters were never set "
+                    "(opty_hip_set_known_parameters)");
+    if (p->d.m_known > 0 && !p->have_known)
+        return fail("known trajectories were never set "
+                    "(opty_hip_set_known_trajectories)");
+    if (p->d.num_inst > 0 && !p->have_inst)
+        return fail("instance indices were never set "
+                    "(opty_hip_set_instance_indices)");
+    return 0;
+}
+
+int launch(opty_hip_problem *p, hipFunction_t f, int waves_per_block,
+           const double *free_, double *con, double *jac) {
+    KernelArgs a;
+    a.free_ = free_;
+    a.known_traj = p->d_known;
+    a.params = p->d_params;
+    a.uni_c = p->d_uni;
+    a.uni_w = p->d_uni;
+    a.inst_idx = p->d_inst_idx;
+    a.con = con;
+    a.jac = jac;
+    a.h = p->h;
+    a.N = p->d.N;
+    a.con_stride = p->ncon_nodes();
+    a.node_begin = 0;
+    a.node_end = p->ncon_nodes();
+    size_t size = sizeof a;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a,
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                      HIP_LAUNCH_PARAM_END};
+    unsigned grid = 1;
+    if (waves_per_block > 0) {
+        long long nblk = (p->ncon_nodes() + 63)/64;
+        if (waves_per_block > 1)           // XCD-aware mapping pads to 8
+            nblk = ((nblk + 7)/8)*8;
+        grid = (unsigned)(nblk*waves_per_block);
+        if (grid == 0) return 0;
+    }
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, p->stream,
+                                  nullptr, config));
+    return 0;
+}
+
+// what: OPTY_HIP_EVAL_*; device pointers only
+int eval_device(opty_hip_problem *p, int what, const double *free_,
+                double *con, double *jac) {
+    const int G = p->d.jac_groups;
+    // Node-invariant sub-expressions: recomputed only when their inputs can
+    // have changed (always, if they read unknown parameters / h from `free`).
+    if (p->d.num_uniform > 0 && (p->uni_dirty || p->d.uniform_dynamic)) {
+        if (int rc = launch(p, p->k_uni, 0, free_, nullptr, nullptr)) return rc;
+        p->uni_dirty = false;
+    }
+    if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
+        if (int rc = launch(p, p->k_con, 1, free_, con, nullptr)) return rc;
+    if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
+        if (int rc = launch(p, p->k_jac, G, free_, nullptr, jac)) return rc;
+    if (what == OPTY_HIP_EVAL_FUSED)
+        if (int rc = launch(p, p->k_conjac, G, free_, con, jac)) return rc;
+    if (p->d.num_inst > 0) {
+        double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr : con;
+        double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr : jac;
+        if (int rc = launch(p, p->k_inst, 0, free_, c, j)) return rc;
+    }
+    return 0;
+}
+
+template <typename T>
+int ensure(T **ptr, size_t count) {
+    if (*ptr == nullptr && count > 0)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(ptr), count*sizeof(T)));
+    return 0;
+}
+
+int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
+             double *jac, int mem) {
+    if (!p) return fail("null handle");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    const bool want_con = what != OPTY_HIP_EVAL_JAC;
+    const bool want_jac = what != OPTY_HIP_EVAL_CON;
+    if (!free_ || (want_con && !con) || (want_jac && !jac))
+        return fail("null buffer");
+    if (mem == OPTY_HIP_DEVICE)
+        return eval_device(p, what, free_, con, jac);
+    if (mem != OPTY_HIP_HOST) return fail("bad memory kind %d", mem);
+    // Host buffers (the cyipopt callback case): stage through device memory.
+    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+    if (want_con)
+        if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
+    if (want_jac)
+        if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
+                           hipMemcpyHostToDevice, p->stream));
+    if (int rc = eval_device(p, what, p->d_free, p->d_con, p->d_jac))
+        return rc;
+    if (want_con)
+        HIP_TRY(hipMemcpyAsync(con, p->d_con, p->num_con()*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    if (want_jac)
+        HIP_TRY(hipMemcpyAsync(jac, p->d_jac, p->nnz()*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *opty_hip_last_error(void) { return g_error.c_str(); }
+
+int opty_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
+                    opty_hip_problem **out) {
+    if (!desc || !code_object_path || !out) return fail("null argument");
+    if (desc->N < 2) return fail("need at least 2 collocation nodes");
+    if (desc->jac_groups < 1) return fail("jac_groups must be >= 1");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail("no HIP device is visible: the HIP backend has no CPU "
+                    "fallback");
+    if (desc->device < 0 || desc->device >= count)
+        return fail("device %d out of range (have %d)", desc->device, count);
+    HIP_TRY(hipSetDevice(desc->device));
+    auto *p = new opty_hip_problem;
+    p->d = *desc;
+    hipError_t e = hipModuleLoad(&p->module, code_object_path);
+    if (e != hipSuccess) {
+        delete p;
+        return fail("hipModuleLoad(%s) failed: %s", code_object_path,
+                    hipGetErrorString(e));
+    }
+    struct { const char *name; hipFunction_t *f; bool required; } ks[] = {
+        {"opty_con", &p->k_con, true},
+        {"opty_jac", &p->k_jac, true},
+        {"opty_conjac", &p->k_conjac, true},
+        {"opty_inst", &p->k_inst, desc->num_inst > 0},
+        {"opty_uni", &p->k_uni, desc->num_uniform > 0},
+    };
+    for (auto &k : ks) {
+        if (!k.required) continue;
+        e = hipModuleGetFunction(k.f, p->module, k.name);
+        if (e != hipSuccess) {
+            (void)hipModuleUnload(p->module);
+            delete p;
+            return fail("kernel %s missing from %s: %s", k.name,
+                        code_object_path, hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    p->stream = p->own_stream;
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    if (desc->p_known > 0)
+        HIP_TRY(hipMalloc((void **)&p->d_params,
+                          desc->p_known*sizeof(double)));
+    if (desc->num_uniform > 0)
+        HIP_TRY(hipMalloc((void **)&p->d_uni,
+                          desc->num_uniform*sizeof(double)));
+    if (desc->m_known > 0)
+        HIP_TRY(hipMalloc((void **)&p->d_known,
+                          (size_t)desc->m_known*desc->N*sizeof(double)));
+    *out = p;
+    return 0;
+}
+
+int opty_hip_destroy(opty_hip_problem *p) {
+    if (!p) return 0;
+    (void)hipSetDevice(p->d.device);
+    (void)hipStreamSynchronize(p->stream);
+    void *bufs[] = {p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
+                    p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
+                    p->d_cols};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->module) (void)hipModuleUnload(p->module);
+    delete p;
+    return 0;
+}
+
+int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream) {
+    if (!p) return fail("null handle");
+    p->stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+    return 0;
+}
+
+int opty_hip_synchronize(opty_hip_problem *p) {
+    if (!p) return fail("null handle");
+    if (int rc = use_device(p)) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
+                                  int32_t count) {
+    if (!p) return fail("null handle");
+    if (count != p->d.p_known)
+        return fail("expected %d known parameters, got %d", p->d.p_known,
+                    count);
+    if (count == 0) return 0;
+    if (!values) return fail("null values");
+    if (int rc = use_device(p)) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_params, values, count*sizeof(double),
+                           hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->uni_dirty = true;
+    p->have_params = true;
+    return 0;
+}
+
+int opty_hip_set_interval(opty_hip_problem *p, double h) {
+    if (!p) return fail("null handle");
+    p->h = h;
+    p->uni_dirty = true;
+    return 0;
+}
+
+int opty_hip_set_known_trajectories(opty_hip_problem *p, const double *values,
+                                    int32_t mem) {
+    if (!p) return fail("null handle");
+    if (p->d.m_known == 0) return 0;
+    if (!values) return fail("null values");
+    if (int rc = use_device(p)) return rc;
+    const size_t bytes = (size_t)p->d.m_known*p->d.N*sizeof(double);
+    HIP_TRY(hipMemcpyAsync(p->d_known, values, bytes,
+                           mem == OPTY_HIP_DEVICE ? hipMemcpyDeviceToDevice
+                                                  : hipMemcpyHostToDevice,
+                           p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->have_known = true;
+    return 0;
+}
+
+int opty_hip_set_instance_indices(opty_hip_problem *p,
+                                  const int64_t *atom_free_index,
+                                  const int64_t *rows, const int64_t *cols) {
+    if (!p) return fail("null handle");
+    if (p->d.num_inst == 0) return 0;
+    if (int rc = use_device(p)) return rc;
+    const int na = p->d.num_inst_atoms, nz = p->d.nnz_inst;
+    if (na > 0 && !atom_free_index) return fail("null atom index table");
+    if (nz > 0 && (!rows || !cols)) return fail("null instance rows/cols");
+    for (int a = 0; a < na; ++a)
+        if (atom_free_index[a] < 0 || atom_free_index[a] >= p->num_free())
+            return fail("instance atom %d: free index %lld out of range", a,
+                        (long long)atom_free_index[a]);
+    if (int rc = ensure(&p->d_inst_idx, (size_t)na)) return rc;
+    if (int rc = ensure(&p->d_inst_rows, (size_t)nz)) return rc;
+    if (int rc = ensure(&p->d_inst_cols, (size_t)nz)) return rc;
+    if (na)
+        HIP_TRY(hipMemcpy(p->d_inst_idx, atom_free_index, na*sizeof(int64_t),
+                          hipMemcpyHostToDevice));
+    if (nz) {
+        HIP_TRY(hipMemcpy(p->d_inst_rows, rows, nz*sizeof(int64_t),
+                          hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->d_inst_cols, cols, nz*sizeof(int64_t),
+                          hipMemcpyHostToDevice));
+    }
+    p->have_inst = true;
+    return 0;
+}
+
+int64_t opty_hip_num_free(const opty_hip_problem *p) {
+    return p ? p->num_free() : -1;
+}
+int64_t opty_hip_num_constraints(const opty_hip_problem *p) {
+    return p ? p->num_con() : -1;
+}
+int64_t opty_hip_nnz(const opty_hip_problem *p) { return p ? p->nnz() : -1; }
+
+int opty_hip_eval_con(opty_hip_problem *p, const double *free_, double *con,
+                      int32_t mem) {
+    return eval_any(p, OPTY_HIP_EVAL_CON, free_, con, nullptr, mem);
+}
+
+int opty_hip_eval_jac(opty_hip_problem *p, const double *free_, double *jac,
+                      int32_t mem) {
+    return eval_any(p, OPTY_HIP_EVAL_JAC, free_, nullptr, jac, mem);
+}
+
+int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free_,
+                          double *con, double *jac, int32_t mem) {
+    return eval_any(p, OPTY_HIP_EVAL_FUSED, free_, con, jac, mem);
+}
+
+int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
+                              int64_t *cols, int32_t mem) {
+    if (!p) return fail("null handle");
+    if (!rows || !cols) return fail("null buffer");
+    if (int rc = use_device(p)) return rc;
+    if (p->d.num_inst > 0 && !p->have_inst)
+        return fail("instance indices were never set");
+    long long *dr = (long long *)rows, *dc = (long long *)cols;
+    const size_t nnz = (size_t)p->nnz();
+    if (mem == OPTY_HIP_HOST) {
+        if (int rc = ensure(&p->d_rows, nnz)) return rc;
+        if (int rc = ensure(&p->d_cols, nnz)) return rc;
+        dr = p->d_rows;
+        dc = p->d_cols;
+    } else if (mem != OPTY_HIP_DEVICE) {
+        return fail("bad memory kind %d", mem);
+    }
+    IndexDims d;
+    d.N = p->d.N;
+    d.ncon = p->ncon_nodes();
+    d.n = p->d.n;
+    d.q = p->d.q;
+    d.M = p->d.M;
+    d.C = p->d.C;
+    d.tail = p->d.r + p->d.s;
+    d.method = p->d.method;
+    const int P = (int)p->P();
+    // enough entries per block to keep 256 lanes busy
+    int npb = P >= 1024 ? 1 : (1024 + P - 1)/P;
+    const unsigned grid = (unsigned)((d.ncon + npb - 1)/npb);
+    hipLaunchKernelGGL(opty_indices_kernel, dim3(grid), dim3(256), 0,
+                       p->stream, d, dr, dc, npb);
+    HIP_TRY(hipGetLastError());
+    const size_t base = (size_t)(p->P()*p->ncon_nodes());
+    if (p->d.nnz_inst > 0) {
+        HIP_TRY(hipMemcpyAsync(dr + base, p->d_inst_rows,
+                               p->d.nnz_inst*sizeof(int64_t),
+                               hipMemcpyDeviceToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(dc + base, p->d_inst_cols,
+                               p->d.nnz_inst*sizeof(int64_t),
+                               hipMemcpyDeviceToDevice, p->stream));
+    }
+    if (mem == OPTY_HIP_HOST) {
+        HIP_TRY(hipMemcpyAsync(rows, dr, nnz*sizeof(int64_t),
+                               hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipMemcpyAsync(cols, dc, nnz*sizeof(int64_t),
+                               hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        // index arrays are setup-only: do not keep 16 bytes/entry resident
+        (void)hipFree(p->d_rows);
+        (void)hipFree(p->d_cols);
+        p->d_rows = p->d_cols = nullptr;
+    }
+    return 0;
+}
+
+int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
+                       double *con, double *jac, int32_t iters,
+                       float *ms_per_iter) {
+    if (!p || !ms_per_iter) return fail("null argument");
+    if (iters < 1) return fail("iters must be >= 1");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    if (p->d.num_uniform > 0 && p->uni_dirty && !p->d.uniform_dynamic) {
+        // keep the one-off table fill out of the timed region
+        if (int rc = launch(p, p->k_uni, 0, free_, nullptr, nullptr)) return rc;
+        p->uni_dirty = false;
+    }
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    for (int it = 0; it < iters; ++it)
+        if (int rc = eval_device(p, what, free_, con, jac)) return rc;
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
+    *ms_per_iter = ms/iters;
+    return 0;
+}
+
+}  // extern "C"

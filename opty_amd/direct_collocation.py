@@ -1,0 +1,736 @@
+"""``ConstraintCollocator`` / ``Problem`` with the reference's API surface
+(``opty/direct_collocation.py:93-145``, ``:1379-1411``) and one backend:
+``'hip'`` -- hand-scheduled gfx950 kernels generated per problem by
+:mod:`opty_amd.codegen` and run through ``libopty_hip.so``.
+
+The host-side transcription (symbol classification, discrete symbols,
+discretisation, argument / ``wrt`` ordering, instance-constraint index map)
+follows the reference's rules so that ``constraints(free)``,
+``jacobian(free)`` and ``jacobian_indices()`` have identical layouts:
+
+* unknown parameters / trajectories are name-sorted, known ones keep the
+  order of the user's dictionaries (``opty/direct_collocation.py:1940-1950``);
+* backward Euler: ``x' -> (x_i - x_p)/h``; midpoint: ``x' -> (x_n - x_i)/h``,
+  ``x -> (x_i + x_n)/2`` (``:2143-2156``);
+* ``wrt`` = ``x_i, x_p|x_n, u_i[, u_n], p_unknown[, h]`` (``:2719-2737``).
+"""
+
+import logging
+
+import numpy as np
+import sympy as sm
+import sympy.physics.mechanics as me
+
+from .utils import parse_free, sort_sympy
+from .codegen.program import build_program
+from .codegen.emit_hip import emit_module, EmitOptions
+from . import hip_backend as hb
+
+__all__ = ['Problem', 'ConstraintCollocator']
+
+logger = logging.getLogger(__name__)
+
+_METHODS = ('backward euler', 'midpoint')
+
+
+class ConstraintCollocator(object):
+    """Generates the constraint function and the sparse Jacobian of the
+    constraint function of a direct-collocation transcription, evaluated on an
+    MI355X.
+
+    Same constructor arguments, attributes and public methods as the
+    reference's class (``opty/direct_collocation.py:1406-1411``,
+    ``:1556-1892``, ``:2450``, ``:3003-3015``).  Differences:
+
+    * ``backend`` must be ``'hip'`` (default); the reference's CPU backends
+      ``'cython'`` / ``'numpy'`` do not exist here;
+    * ``parallel`` is accepted and ignored (a GPU launch is always parallel);
+    * ``tmp_dir`` is the code-object cache directory;
+    * extra keyword ``device`` (HIP ordinal) and ``emit_options``.
+
+    Notation: N nodes, M equations, n states, m input trajectories, q unknown
+    input trajectories, r unknown parameters, s variable duration, o instance
+    constraints.
+    """
+
+    def __init__(self, equations_of_motion, state_symbols,
+                 num_collocation_nodes, node_time_interval,
+                 known_parameter_map={}, known_trajectory_map={},
+                 instance_constraints=None, time_symbol=None, tmp_dir=None,
+                 integration_method='backward euler', parallel=False,
+                 show_compile_output=False, backend='hip', device=0,
+                 emit_options=None):
+        self._eom = sm.ImmutableDenseMatrix(equations_of_motion)
+        if self._eom.shape[1] != 1:
+            raise ValueError('equations_of_motion must be a column matrix.')
+        if time_symbol is not None:
+            self._time_symbol = time_symbol
+            # the reference also re-points mechanics' global time symbol
+            # (opty/direct_collocation.py:1490-1494)
+            me.dynamicsymbols._t = time_symbol
+        else:
+            self._time_symbol = me.dynamicsymbols._t
+
+        self._state_symbols = tuple(state_symbols)
+        if len(self.state_symbols) != len(set(self.state_symbols)):
+            raise ValueError('State symbols must be unique.')
+        if backend != 'hip':
+            raise ValueError('backend must be "hip" (this build has no '
+                             '"cython"/"numpy" CPU backends).')
+        self._state_derivative_symbols = tuple(
+            s.diff(self.time_symbol) for s in self.state_symbols)
+        self._num_collocation_nodes = int(num_collocation_nodes)
+
+        if isinstance(node_time_interval, sm.Symbol):
+            self._time_interval_symbol = node_time_interval
+            self._variable_duration = True
+        else:
+            self._time_interval_symbol = sm.Symbol('h_opty', real=True)
+            self._variable_duration = False
+        self._node_time_interval = node_time_interval
+
+        self._known_parameter_map = known_parameter_map
+        self._known_trajectory_map = known_trajectory_map
+        self._instance_constraints = instance_constraints
+        self._num_constraints = self.num_eom*(self.num_collocation_nodes - 1)
+        self._tmp_dir = tmp_dir
+        self._parallel = parallel
+        self._show_compile_output = show_compile_output
+        self._backend = backend
+        self._device = int(device)
+        self._emit_options = emit_options or EmitOptions()
+
+        self._sort_parameters()
+        self._sort_trajectories()
+        self._num_free = ((self.num_states +
+                           self.num_unknown_input_trajectories) *
+                          self.num_collocation_nodes +
+                          self.num_unknown_parameters +
+                          int(self._variable_duration))
+        self._check_known_trajectories()
+
+        if integration_method not in _METHODS:
+            raise ValueError('{} is not a valid integration method.'
+                             .format(integration_method))
+        self._integration_method = integration_method
+        self._discrete_symbols()
+        self._discretize_eom()
+
+        if instance_constraints is not None:
+            self._num_instance_constraints = len(instance_constraints)
+            self._num_constraints += self.num_instance_constraints
+            self._identify_functions_in_instance_constraints()
+            self._find_closest_free_index()
+            self._order_instance_atoms()
+        else:
+            self._num_instance_constraints = 0
+            self._inst_atoms = []
+            self._inst_rows = np.zeros(0, dtype=np.int64)
+            self._inst_cols = np.zeros(0, dtype=np.int64)
+
+        self._program = None
+        self._hip = None
+
+    # ------------------------------------------------------------------
+    # public attributes (names as in opty/direct_collocation.py:1556-1892)
+    # ------------------------------------------------------------------
+    eom = property(lambda self: self._eom)
+    time_symbol = property(lambda self: self._time_symbol)
+    state_symbols = property(lambda self: self._state_symbols)
+    state_derivative_symbols = property(
+        lambda self: self._state_derivative_symbols)
+    num_collocation_nodes = property(
+        lambda self: self._num_collocation_nodes)
+    node_time_interval = property(lambda self: self._node_time_interval)
+    time_interval_symbol = property(lambda self: self._time_interval_symbol)
+    known_parameter_map = property(lambda self: self._known_parameter_map)
+    known_trajectory_map = property(lambda self: self._known_trajectory_map)
+    instance_constraints = property(lambda self: self._instance_constraints)
+    num_constraints = property(lambda self: self._num_constraints)
+    num_free = property(lambda self: self._num_free)
+    num_instance_constraints = property(
+        lambda self: self._num_instance_constraints)
+    tmp_dir = property(lambda self: self._tmp_dir)
+    parallel = property(lambda self: self._parallel)
+    show_compile_output = property(lambda self: self._show_compile_output)
+    discrete_eom = property(lambda self: self._discrete_eom)
+    known_parameters = property(lambda self: self._known_parameters)
+    num_known_parameters = property(lambda self: len(self._known_parameters))
+    unknown_parameters = property(lambda self: self._unknown_parameters)
+    num_unknown_parameters = property(
+        lambda self: len(self._unknown_parameters))
+    parameters = property(lambda self: self._parameters)
+    num_parameters = property(lambda self: len(self._parameters))
+    known_input_trajectories = property(
+        lambda self: self._known_input_trajectories)
+    num_known_input_trajectories = property(
+        lambda self: len(self._known_input_trajectories))
+    unknown_input_trajectories = property(
+        lambda self: self._unknown_input_trajectories)
+    num_unknown_input_trajectories = property(
+        lambda self: len(self._unknown_input_trajectories))
+    input_trajectories = property(lambda self: self._input_trajectories)
+    num_input_trajectories = property(
+        lambda self: len(self._input_trajectories))
+    previous_discrete_state_symbols = property(
+        lambda self: self._previous_discrete_state_symbols)
+    current_discrete_state_symbols = property(
+        lambda self: self._current_discrete_state_symbols)
+    next_discrete_state_symbols = property(
+        lambda self: self._next_discrete_state_symbols)
+    current_known_discrete_specified_symbols = property(
+        lambda self: self._current_known_discrete_specified_symbols)
+    next_known_discrete_specified_symbols = property(
+        lambda self: self._next_known_discrete_specified_symbols)
+    current_unknown_discrete_specified_symbols = property(
+        lambda self: self._current_unknown_discrete_specified_symbols)
+    next_unknown_discrete_specified_symbols = property(
+        lambda self: self._next_unknown_discrete_specified_symbols)
+    current_discrete_specified_symbols = property(
+        lambda self: self._current_discrete_specified_symbols)
+    next_discrete_specified_symbols = property(
+        lambda self: self._next_discrete_specified_symbols)
+
+    @property
+    def num_eom(self):
+        return self._eom.shape[0]
+
+    @property
+    def num_states(self):
+        return len(self._state_symbols)
+
+    @property
+    def integration_method(self):
+        return self._integration_method
+
+    @integration_method.setter
+    def integration_method(self, method):
+        if method not in _METHODS:
+            raise ValueError('{} is not a valid integration method.'
+                             .format(method))
+        self._integration_method = method
+        self._discretize_eom()
+        self._program = None
+        self._hip = None
+
+    @property
+    def num_block_columns(self):
+        """C: columns of the per-node dense block (``len(wrt)``)."""
+        q = self.num_unknown_input_trajectories
+        return (2*self.num_states +
+                (q if self.integration_method == 'backward euler' else 2*q) +
+                self.num_unknown_parameters + int(self._variable_duration))
+
+    # ------------------------------------------------------------------
+    # symbol classification (opty/direct_collocation.py:1904-2035)
+    # ------------------------------------------------------------------
+    @staticmethod
+    def _parse_inputs(all_syms, known_syms):
+        """-> (known, unknown): known in the user's order, unknown sorted."""
+        pool = set(all_syms)
+        known_syms = list(known_syms)
+        if not pool:
+            if known_syms:
+                raise ValueError('{} are not in the provided equations of '
+                                 'motion.'.format(known_syms))
+            return (), ()
+        known = tuple(known_syms)
+        return known, tuple(sort_sympy(pool.difference(known)))
+
+    def _sort_parameters(self):
+        pool = set(self.eom.free_symbols)
+        pool.discard(self.time_symbol)
+        known, unknown = self._parse_inputs(pool,
+                                            self.known_parameter_map.keys())
+        self._known_parameters = known
+        self._unknown_parameters = unknown
+        self._parameters = known + unknown
+
+    def _sort_trajectories(self):
+        state_related = set(self.state_symbols).union(
+            self.state_derivative_symbols)
+        non_states = me.find_dynamicsymbols(self.eom).difference(
+            state_related)
+        if any(isinstance(f, sm.Derivative) for f in non_states):
+            raise ValueError('Too few state variables provided for state '
+                             'time derivatives found in equations of motion.')
+        for f in non_states:
+            if len(f.args) > 1:
+                raise ValueError(f'{f} is a function of more than one '
+                                 'variable.')
+            if f.args != (self.time_symbol,):
+                # implicit known trajectories r(x(t)) with chain-rule symbols
+                # (opty/direct_collocation.py:2080-2093, :2284-2302) are a
+                # "next" row of SURVEY.md 8(f), not built yet.
+                raise NotImplementedError(
+                    f'{f}: known trajectories that are functions of a state '
+                    'are not supported by the HIP backend yet.')
+        names = [f.name for f in non_states]
+        if len(names) != len(set(names)):
+            raise ValueError('Repeated input trajectory variable fnames not '
+                             f'allowed: {names}')
+        known, unknown = self._parse_inputs(non_states,
+                                            self.known_trajectory_map.keys())
+        self._known_input_trajectories = known
+        self._unknown_input_trajectories = unknown
+        self._input_trajectories = known + unknown
+
+    def _check_known_trajectories(self):
+        N = self.num_collocation_nodes
+        for k, v in self.known_trajectory_map.items():
+            if callable(v):
+                v = v(np.ones(self.num_free))
+            if len(v) != N:
+                raise ValueError('The known parameter {} is not length {}.'
+                                 .format(k, N))
+
+    # ------------------------------------------------------------------
+    # discretisation (opty/direct_collocation.py:2037-2156)
+    # ------------------------------------------------------------------
+    def _discrete_symbols(self):
+        def tagged(funcs, tag):
+            return tuple(sm.Symbol(f.__class__.__name__ + tag, real=True)
+                         for f in funcs)
+        self._previous_discrete_state_symbols = tagged(self.state_symbols,
+                                                       'p')
+        self._current_discrete_state_symbols = tagged(self.state_symbols, 'i')
+        self._next_discrete_state_symbols = tagged(self.state_symbols, 'n')
+        self._current_known_discrete_specified_symbols = tagged(
+            self.known_input_trajectories, 'i')
+        self._next_known_discrete_specified_symbols = tagged(
+            self.known_input_trajectories, 'n')
+        self._current_unknown_discrete_specified_symbols = tagged(
+            self.unknown_input_trajectories, 'i')
+        self._next_unknown_discrete_specified_symbols = tagged(
+            self.unknown_input_trajectories, 'n')
+        self._current_discrete_specified_symbols = (
+            self._current_known_discrete_specified_symbols +
+            self._current_unknown_discrete_specified_symbols)
+        self._next_discrete_specified_symbols = (
+            self._next_known_discrete_specified_symbols +
+            self._next_unknown_discrete_specified_symbols)
+
+    def _discretize_eom(self):
+        logger.info('Discretizing the equations of motion.')
+        x, xd = self.state_symbols, self.state_derivative_symbols
+        u = self.input_trajectories
+        xp = self.previous_discrete_state_symbols
+        xi = self.current_discrete_state_symbols
+        xn = self.next_discrete_state_symbols
+        ui = self.current_discrete_specified_symbols
+        un = self.next_discrete_specified_symbols
+        h = self.time_interval_symbol
+        rules = {}
+        if self.integration_method == 'backward euler':
+            for d, cur, prev in zip(xd, xi, xp):
+                rules[d] = (cur - prev)/h
+            rules.update(zip(x + u, xi + ui))
+        else:
+            for d, cur, nxt in zip(xd, xi, xn):
+                rules[d] = (nxt - cur)/h
+            for f, cur, nxt in zip(x + u, xi + ui, xn + un):
+                rules[f] = (cur + nxt)/2
+        # one top-down pass: derivatives are matched before their arguments
+        self._discrete_eom = self.eom.xreplace(rules)
+
+    # ------------------------------------------------------------------
+    # instance constraints (opty/direct_collocation.py:2158-2282)
+    # ------------------------------------------------------------------
+    def _identify_functions_in_instance_constraints(self):
+        atoms = set()
+        for con in self.instance_constraints:
+            atoms |= con.atoms(sm.Function)
+        self.instance_constraint_function_atoms = atoms
+
+    def _find_closest_free_index(self):
+        N, n = self.num_collocation_nodes, self.num_states
+        node_map = {}
+        time_vector = None
+        for func in self.instance_constraint_function_atoms:
+            arg = func.args[0]
+            if self._variable_duration:
+                if arg == 0:
+                    time_idx = 0
+                else:
+                    try:
+                        time_idx = int(arg/self.time_interval_symbol)
+                    except TypeError as err:
+                        raise TypeError(
+                            'Instance constraint {} is not a correct integer '
+                            'multiple of the time interval.'.format(func)
+                        ) from err
+                if time_idx not in range(N):
+                    raise ValueError(
+                        'Instance constraint {} gives an index of {} which '
+                        'is not between 0 and {}.'.format(func, time_idx,
+                                                          N - 1))
+            else:
+                if time_vector is None:
+                    time_vector = np.linspace(
+                        0.0, self.node_time_interval*(N - 1), num=N)
+                time_idx = int(np.argmin(np.abs(time_vector - float(arg))))
+            base = func.__class__(self.time_symbol)
+            if base in self.state_symbols:
+                row = self.state_symbols.index(base)
+            elif base in self.unknown_input_trajectories:
+                row = n + self.unknown_input_trajectories.index(base)
+            else:
+                raise ValueError(f'{func} in an instance constraint is '
+                                 'neither a state nor an unknown input '
+                                 'trajectory.')
+            node_map[func] = time_idx + row*N
+        self.instance_constraints_free_index_map = node_map
+
+    def _order_instance_atoms(self):
+        """Fixes a deterministic atom order (by free index).  The reference
+        iterates ``con.atoms(sm.Function)``, a set, so its order is only
+        defined for single-atom constraints; those agree."""
+        idx = self.instance_constraints_free_index_map
+        self._inst_atoms = sorted(idx, key=lambda f: (idx[f], str(f)))
+        per_con = []
+        rows, cols = [], []
+        base = self.num_eom*(self.num_collocation_nodes - 1)
+        for i, con in enumerate(self.instance_constraints):
+            atoms = sorted(con.atoms(sm.Function),
+                           key=lambda f: (idx[f], str(f)))
+            per_con.append(atoms)
+            rows += [base + i]*len(atoms)
+            cols += [idx[f] for f in atoms]
+        self._inst_atoms_per_constraint = per_con
+        self._inst_rows = np.array(rows, dtype=np.int64)
+        self._inst_cols = np.array(cols, dtype=np.int64)
+
+    def _instance_constraints_jacobian_indices(self):
+        return self._inst_rows.copy(), self._inst_cols.copy()
+
+    # ------------------------------------------------------------------
+    # HIP program (replaces opty/direct_collocation.py:2304-2380, :2692-2814)
+    # ------------------------------------------------------------------
+    def _wrt(self):
+        if self.integration_method == 'backward euler':
+            wrt = (self.current_discrete_state_symbols +
+                   self.previous_discrete_state_symbols +
+                   self.current_unknown_discrete_specified_symbols +
+                   self.unknown_parameters)
+        else:
+            wrt = (self.current_discrete_state_symbols +
+                   self.next_discrete_state_symbols +
+                   self.current_unknown_discrete_specified_symbols +
+                   self.next_unknown_discrete_specified_symbols +
+                   self.unknown_parameters)
+        if self._variable_duration:
+            wrt += (self.time_interval_symbol,)
+        return wrt
+
+    def _build_program(self):
+        if self._program is not None:
+            return self._program
+        be = self.integration_method == 'backward euler'
+        instance = None
+        if self.instance_constraints is not None:
+            place = {f: sm.Symbol('opty_atom_%d' % a, real=True)
+                     for a, f in enumerate(self._inst_atoms)}
+            exprs = [sm.sympify(c).xreplace(place)
+                     for c in self.instance_constraints]
+            grads = [[place[f] for f in atoms]
+                     for atoms in self._inst_atoms_per_constraint]
+            instance = (exprs, [place[f] for f in self._inst_atoms], grads)
+        logger.info('Lowering and differentiating the constraint function.')
+        self._program = build_program(
+            list(self.discrete_eom),
+            self.current_discrete_state_symbols,
+            self.previous_discrete_state_symbols if be
+            else self.next_discrete_state_symbols,
+            self.current_discrete_specified_symbols,
+            self.next_discrete_specified_symbols,
+            self.num_known_input_trajectories,
+            self.parameters, self.num_known_parameters,
+            self.time_interval_symbol, self._variable_duration,
+            self._wrt(), self.integration_method, instance)
+        return self._program
+
+    def generate_source(self):
+        """HIP source of this problem's kernels and its launch metadata."""
+        return emit_module(self._build_program(), self._emit_options)
+
+    def _descriptor(self, meta):
+        prog = self._program
+        return dict(
+            N=self.num_collocation_nodes, n=self.num_states, M=self.num_eom,
+            m_known=self.num_known_input_trajectories,
+            q=self.num_unknown_input_trajectories,
+            p_known=self.num_known_parameters,
+            r=self.num_unknown_parameters, s=int(self._variable_duration),
+            C=prog.C,
+            method=0 if self.integration_method == 'backward euler' else 1,
+            num_inst=self.num_instance_constraints,
+            nnz_inst=len(self._inst_rows),
+            num_inst_atoms=len(self._inst_atoms),
+            jac_groups=meta['kernels']['jac']['groups'],
+            num_uniform=meta['num_uniform'],
+            uniform_dynamic=int(meta['uniform_dynamic']),
+            device=self._device)
+
+    def _known_trajectory_array(self, free):
+        vals = []
+        for f in self.known_input_trajectories:
+            v = self.known_trajectory_map[f]
+            vals.append(v(free) if callable(v) else v)
+        return np.array(vals, dtype=np.float64)
+
+    def _ensure_hip(self):
+        """Builds (or fetches from the cache) the code object, creates the
+        device handle and uploads the node-invariant data."""
+        if self._hip is not None:
+            return self._hip
+        source, meta = self.generate_source()
+        logger.info('Compiling the HIP constraint/Jacobian kernels.')
+        hsaco = hb.compile_module(source, self.tmp_dir,
+                                  self.show_compile_output)
+        hip = hb.HipProblem(self._descriptor(meta), hsaco)
+        hip.set_known_parameters([float(self.known_parameter_map[p])
+                                  for p in self.known_parameters])
+        if not self._variable_duration:
+            hip.set_interval(self.node_time_interval)
+        self._callable_known = any(
+            callable(v) for v in self.known_trajectory_map.values())
+        if self.num_known_input_trajectories and not self._callable_known:
+            hip.set_known_trajectories(self._known_trajectory_array(None))
+        if self.num_instance_constraints:
+            idx = self.instance_constraints_free_index_map
+            hip.set_instance_indices([idx[f] for f in self._inst_atoms],
+                                     self._inst_rows, self._inst_cols)
+        self._kernel_meta = meta
+        self._hip = hip
+        return hip
+
+    @property
+    def hip(self):
+        """The :class:`opty_amd.hip_backend.HipProblem` handle (device-pointer
+        evaluation, timing)."""
+        return self._ensure_hip()
+
+    def _refresh_callable_known(self, hip, free):
+        # known trajectories given as functions of ``free``
+        # (opty/direct_collocation.py:2916-2917) are re-evaluated on the host
+        # and re-uploaded on every call.
+        if self.num_known_input_trajectories and self._callable_known:
+            hip.set_known_trajectories(self._known_trajectory_array(free))
+
+    def _host_free(self, free):
+        free = np.ascontiguousarray(free, dtype=np.float64)
+        if free.shape != (self.num_free,):
+            raise ValueError('free must have shape ({},), got {}'.format(
+                self.num_free, free.shape))
+        return free
+
+    # ------------------------------------------------------------------
+    # public evaluation API (opty/direct_collocation.py:3003-3015, :2450)
+    # ------------------------------------------------------------------
+    def generate_constraint_function(self):
+        """Returns ``f(free) -> ndarray (M*(N-1) + o,)``: the constraints,
+        equation-major, followed by the instance constraints."""
+        logger.info('Generating constraint function.')
+        hip = self._ensure_hip()
+
+        def constraints(free):
+            free = self._host_free(free)
+            self._refresh_callable_known(hip, free)
+            out = np.empty(self.num_constraints)      # fresh, as :2444
+            hip.eval_con(free, out, hb.HOST)
+            return out
+        return constraints
+
+    def generate_jacobian_function(self):
+        """Returns ``f(free) -> ndarray (M*C*(N-1) + nnz_inst,)``: the dense
+        per-node blocks, node-major, followed by the instance partials.  The
+        returned array is a persistent buffer that the next call overwrites
+        (as in the reference, ``:2814``, ``:2887``)."""
+        logger.info('Generating jacobian function.')
+        hip = self._ensure_hip()
+        result = np.empty(hip.nnz)
+
+        def jacobian(free):
+            free = self._host_free(free)
+            self._refresh_callable_known(hip, free)
+            hip.eval_jac(free, result, hb.HOST)
+            return result
+        return jacobian
+
+    def jacobian_indices(self):
+        """Row and column indices (int64) of every Jacobian value, in the
+        order ``generate_jacobian_function`` returns them."""
+        hip = self._ensure_hip()
+        rows = np.empty(hip.nnz, dtype=np.int64)
+        cols = np.empty(hip.nnz, dtype=np.int64)
+        hip.jacobian_indices(rows, cols, hb.HOST)
+        return rows, cols
+
+    # host helpers with the reference's names ---------------------------
+    def eval_instance_constraints(self, free):
+        con = self.generate_constraint_function()(free)
+        return con[self.num_eom*(self.num_collocation_nodes - 1):]
+
+    def eval_instance_constraints_jacobian_values(self, free):
+        jac = self.generate_jacobian_function()(free)
+        return jac[len(jac) - len(self._inst_rows):].copy()
+
+
+class Problem(object):
+    """NLP facade with the reference's constructor and callbacks
+    (``opty/direct_collocation.py:139-145``, ``:442-567``).
+
+    The reference subclasses ``cyipopt.Problem``; ``cyipopt`` is imported
+    lazily here so that the collocator, the callbacks and the bounds arrays
+    work without IPOPT.  ``solve`` needs ``cyipopt``.
+    """
+
+    INF = 10e19
+
+    def __init__(self, obj, obj_grad, equations_of_motion, state_symbols,
+                 num_collocation_nodes, node_time_interval,
+                 known_parameter_map={}, known_trajectory_map={},
+                 instance_constraints=None, time_symbol=None, tmp_dir=None,
+                 integration_method='backward euler', parallel=False,
+                 bounds=None, show_compile_output=False, backend='hip',
+                 eom_bounds=None, device=0):
+        if not sm.Matrix(equations_of_motion).has(sm.Derivative):
+            raise ValueError('No time derivatives are present. The equations '
+                             'of motion must be ordinary differential '
+                             'equations (ODEs) or differential algebraic '
+                             'equations (DAEs).')
+        self.collocator = ConstraintCollocator(
+            equations_of_motion, state_symbols, num_collocation_nodes,
+            node_time_interval, known_parameter_map, known_trajectory_map,
+            instance_constraints, time_symbol, tmp_dir, integration_method,
+            parallel, show_compile_output=show_compile_output,
+            backend=backend, device=device)
+        self._bounds = bounds
+        if eom_bounds is not None:
+            bad = [k for k in eom_bounds
+                   if k not in range(self.collocator.num_eom)]
+            if bad:
+                raise ValueError(f'Keys {bad} in eom_bounds do not '
+                                 'correspond to equations of motion.')
+        self._eom_bounds = eom_bounds
+
+        def nargs(f):
+            return f.__code__.co_argcount - len(f.__defaults__ or ())
+        self._obj_num_args, self._obj_grad_num_args = nargs(obj), \
+            nargs(obj_grad)
+        if self._obj_num_args not in (1, 2):
+            raise ValueError('The objective function can only have one or '
+                             'two arguments.')
+        if self._obj_grad_num_args not in (1, 2):
+            raise ValueError('The gradient function can only have one or two'
+                             ' arguments.')
+        self.obj, self.obj_grad = obj, obj_grad
+        self.con = self.collocator.generate_constraint_function()
+        self.con_jac = self.collocator.generate_jacobian_function()
+        self.con_jac_rows, self.con_jac_cols = \
+            self.collocator.jacobian_indices()
+        self.num_free = self.collocator.num_free
+        self.num_constraints = self.collocator.num_constraints
+        self._generate_bound_arrays()
+        self._generate_constraint_bound_arrays()
+        self.obj_value = []
+        self._nlp = None
+
+    bounds = property(lambda self: self._bounds)
+    eom_bounds = property(lambda self: self._eom_bounds)
+
+    # -- bounds (opty/direct_collocation.py:370-440) -----------------------
+    def _generate_constraint_bound_arrays(self):
+        lo = np.zeros(self.num_constraints)
+        hi = np.zeros(self.num_constraints)
+        if self.eom_bounds is not None:
+            span = self.collocator.num_collocation_nodes - 1
+            for j, (a, b) in self.eom_bounds.items():
+                lo[j*span:(j + 1)*span] = a
+                hi[j*span:(j + 1)*span] = b
+        self._low_con_bounds, self._upp_con_bounds = lo, hi
+
+    def _generate_bound_arrays(self):
+        col = self.collocator
+        N = col.num_collocation_nodes
+        lb = -self.INF*np.ones(self.num_free)
+        ub = self.INF*np.ones(self.num_free)
+        tail = N*(col.num_states + col.num_unknown_input_trajectories)
+        for var, (lo, hi) in (self.bounds or {}).items():
+            if var in col.state_symbols:
+                start = col.state_symbols.index(var)*N
+                sl = slice(start, start + N)
+            elif var in col.unknown_input_trajectories:
+                start = (col.num_states +
+                         col.unknown_input_trajectories.index(var))*N
+                sl = slice(start, start + N)
+            elif var in col.unknown_parameters:
+                k = tail + col.unknown_parameters.index(var)
+                sl = slice(k, k + 1)
+            elif (col._variable_duration and
+                  var == col.time_interval_symbol):
+                sl = slice(self.num_free - 1, self.num_free)
+            else:
+                raise ValueError('Bound variable {} not present in free '
+                                 'variables.'.format(var))
+            lb[sl] = lo
+            ub[sl] = hi
+        self.lower_bound, self.upper_bound = lb, ub
+
+    # -- IPOPT callbacks (opty/direct_collocation.py:442-567) ---------------
+    def objective(self, free):
+        return self.obj(*((self, free)[2 - self._obj_num_args:]))
+
+    def gradient(self, free):
+        return self.obj_grad(*((self, free)[2 - self._obj_grad_num_args:]))
+
+    def constraints(self, free):
+        return self.con(free)
+
+    def jacobianstructure(self):
+        return (self.con_jac_rows, self.con_jac_cols)
+
+    def jacobian(self, free):
+        return self.con_jac(free)
+
+    def intermediate(self, *args):
+        self.obj_value.append(args[2])
+
+    # -- helpers ------------------------------------------------------------
+    def parse_free(self, free):
+        col = self.collocator
+        return parse_free(free, col.num_states,
+                          col.num_unknown_input_trajectories,
+                          col.num_collocation_nodes,
+                          variable_duration=col._variable_duration)
+
+    def time_vector(self, solution=None, start_time=0.0):
+        col = self.collocator
+        N = col.num_collocation_nodes
+        if col._variable_duration:
+            if solution is None:
+                raise ValueError('Solution vector must be provided for '
+                                 'variable duration problems.')
+            h = float(solution[-1])
+        else:
+            h = col.node_time_interval
+        return np.linspace(start_time, start_time + (N - 1)*h, num=N)
+
+    def _ipopt(self):
+        if self._nlp is None:
+            try:
+                import cyipopt
+            except ImportError as err:
+                raise ImportError('Problem.solve needs cyipopt (IPOPT), which '
+                                  'is not installed.') from err
+            self._nlp = cyipopt.Problem(
+                n=self.num_free, m=self.num_constraints, problem_obj=self,
+                lb=self.lower_bound, ub=self.upper_bound,
+                cl=self._low_con_bounds, cu=self._upp_con_bounds)
+        return self._nlp
+
+    def add_option(self, *args, **kwargs):
+        return self._ipopt().add_option(*args, **kwargs)
+
+    def solve(self, free, lagrange=[], zl=[], zu=[]):
+        return self._ipopt().solve(free, lagrange=lagrange, zl=zl, zu=zu)

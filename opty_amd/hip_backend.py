@@ -1,0 +1,266 @@
+"""Host side of the HIP backend: build the per-problem gfx950 code object and
+drive ``libopty_hip.so`` (``include/opty_hip.h``) through ``ctypes``.
+
+Counterpart of the build/import half of the reference's ``ufuncify_matrix``
+(``opty/utils.py:814-928``: write files, run ``setup.py build_ext`` in a
+subprocess, import the module, SHA-256 cache keyed on the generated code).
+Here: write ``<sha>.hip``, run ``hipcc --genco`` in a subprocess, keep
+``<sha>.hsaco`` in a cache directory keyed on the source hash.
+
+There is no CPU fallback: if the runtime library or a HIP device is missing
+the constructors raise.
+"""
+
+import ctypes
+import hashlib
+import logging
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_PKG, 'csrc')
+LIB_PATH = os.path.join(_PKG, 'libopty_hip.so')
+DEFAULT_CACHE = os.path.join(_PKG, '_cache')
+ARCH = 'gfx950'
+
+HOST, DEVICE = 0, 1
+EVAL_CON, EVAL_JAC, EVAL_PAIR, EVAL_FUSED = 0, 1, 2, 3
+
+
+class HipBackendError(RuntimeError):
+    pass
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise HipBackendError('hipcc not found; cannot build HIP kernels')
+    return exe
+
+
+def build_runtime_library(force=False):
+    """Compiles ``csrc/opty_hip.cpp`` into ``libopty_hip.so`` (in-tree)."""
+    src = os.path.join(CSRC, 'opty_hip.cpp')
+    deps = [src, os.path.join(_PKG, '..', 'include', 'opty_hip.h')]
+    if (not force and os.path.exists(LIB_PATH) and
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d)
+                for d in deps)):
+        return LIB_PATH
+    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17',
+           '-Wno-unused-value', '-shared', '-fPIC', src, '-o',
+           LIB_PATH + '.tmp']
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise HipBackendError('building libopty_hip.so failed:\n' +
+                              proc.stderr)
+    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    return LIB_PATH
+
+
+def compile_module(source, cache_dir=None, show_compile_output=False,
+                   extra_flags=()):
+    """``hipcc --genco`` of a generated module; returns the ``.hsaco`` path.
+
+    Cached on the SHA-256 of (source, device header, flags) the way the
+    reference caches on ``opty_code_hash`` (``opty/utils.py:759-770``).
+    """
+    cache_dir = os.path.abspath(cache_dir or DEFAULT_CACHE)
+    os.makedirs(cache_dir, exist_ok=True)
+    with open(os.path.join(CSRC, 'opty_device.h')) as f:
+        header = f.read()
+    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17'] + \
+        list(extra_flags)
+    digest = hashlib.sha256(
+        (source + '\0' + header + '\0' + ' '.join(flags)).encode()
+    ).hexdigest()[:24]
+    base = os.path.join(cache_dir, 'opty_' + digest)
+    hsaco = base + '.hsaco'
+    if os.path.exists(hsaco):
+        logger.info('code object cache hit: %s', hsaco)
+        return hsaco
+    with open(base + '.hip', 'w') as f:
+        f.write(source)
+    cmd = [_hipcc()] + flags + ['--genco', '-I', CSRC, base + '.hip', '-o',
+                                hsaco + '.tmp']
+    logger.info('compiling %s', base + '.hip')
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if show_compile_output:
+        print(proc.stdout)
+        print(proc.stderr)
+    if proc.returncode != 0:
+        # mirrors the reference surfacing compiler stderr in an ImportError
+        # (opty/utils.py:912-916)
+        raise ImportError('Unable to build the HIP code object {}, '
+                          'compilation failed. STDERR output from '
+                          'compilation:\n{}'.format(base + '.hip',
+                                                    proc.stderr))
+    os.replace(hsaco + '.tmp', hsaco)
+    return hsaco
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int64)] + [
+        (name, ctypes.c_int32) for name in (
+            'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'method',
+            'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_groups',
+            'num_uniform', 'uniform_dynamic', 'device')]
+
+
+_lib = None
+
+#: every symbol ``include/opty_hip.h`` declares: (restype, argtypes)
+_P = ctypes.c_void_p
+_SIGNATURES = {
+    'opty_hip_create': (ctypes.c_int, [ctypes.POINTER(_Desc),
+                                       ctypes.c_char_p,
+                                       ctypes.POINTER(_P)]),
+    'opty_hip_destroy': (ctypes.c_int, [_P]),
+    'opty_hip_set_stream': (ctypes.c_int, [_P, _P]),
+    'opty_hip_synchronize': (ctypes.c_int, [_P]),
+    'opty_hip_set_known_parameters': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
+    'opty_hip_set_interval': (ctypes.c_int, [_P, ctypes.c_double]),
+    'opty_hip_set_known_trajectories': (ctypes.c_int,
+                                        [_P, _P, ctypes.c_int32]),
+    'opty_hip_set_instance_indices': (ctypes.c_int, [_P, _P, _P, _P]),
+    'opty_hip_num_free': (ctypes.c_int64, [_P]),
+    'opty_hip_num_constraints': (ctypes.c_int64, [_P]),
+    'opty_hip_nnz': (ctypes.c_int64, [_P]),
+    'opty_hip_eval_con': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
+    'opty_hip_eval_jac': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
+    'opty_hip_eval_con_jac': (ctypes.c_int, [_P, _P, _P, _P,
+                                             ctypes.c_int32]),
+    'opty_hip_jacobian_indices': (ctypes.c_int, [_P, _P, _P,
+                                                 ctypes.c_int32]),
+    'opty_hip_time_eval': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P,
+                                          ctypes.c_int32,
+                                          ctypes.POINTER(ctypes.c_float)]),
+    'opty_hip_device_count': (ctypes.c_int, []),
+    'opty_hip_last_error': (ctypes.c_char_p, []),
+}
+
+
+def load_library():
+    """Loads ``libopty_hip.so`` and binds every declared entry point."""
+    global _lib
+    if _lib is None:
+        # PyTorch wheels bundle their own libamdhip64; if torch is going to
+        # live in this process it must load first so that both share ONE HIP
+        # runtime (two runtimes in a process see no devices).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        if not os.path.exists(LIB_PATH):
+            raise HipBackendError(
+                '%s is missing: run `python -c "import __graft_entry__ as g; '
+                'g.build()"` (there is no CPU fallback)' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipBackendError(load_library().opty_hip_last_error().decode())
+
+
+def _ptr(x):
+    """Raw address of a NumPy array, a torch tensor, an int or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, 'data_ptr'):
+        return x.data_ptr()
+    return int(x)
+
+
+class HipProblem(object):
+    """One ``opty_hip_problem`` handle."""
+
+    def __init__(self, desc, hsaco_path):
+        self._lib = load_library()
+        if self._lib.opty_hip_device_count() == 0:
+            raise HipBackendError('no HIP device is visible: the HIP '
+                                  'backend has no CPU fallback')
+        self._h = _P()
+        d = _Desc(**desc)
+        _check(self._lib.opty_hip_create(ctypes.byref(d),
+                                         hsaco_path.encode(),
+                                         ctypes.byref(self._h)))
+        self.desc = dict(desc)
+        self.num_free = self._lib.opty_hip_num_free(self._h)
+        self.num_constraints = self._lib.opty_hip_num_constraints(self._h)
+        self.nnz = self._lib.opty_hip_nnz(self._h)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.opty_hip_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # -- configuration -------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        _check(self._lib.opty_hip_set_stream(self._h, stream_ptr))
+
+    def synchronize(self):
+        _check(self._lib.opty_hip_synchronize(self._h))
+
+    def set_known_parameters(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        _check(self._lib.opty_hip_set_known_parameters(
+            self._h, _ptr(v), len(v)))
+
+    def set_interval(self, h):
+        _check(self._lib.opty_hip_set_interval(self._h, float(h)))
+
+    def set_known_trajectories(self, values):
+        if hasattr(values, 'data_ptr'):
+            _check(self._lib.opty_hip_set_known_trajectories(
+                self._h, _ptr(values), DEVICE))
+            return
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        assert v.size == self.desc['m_known']*self.desc['N']
+        _check(self._lib.opty_hip_set_known_trajectories(
+            self._h, _ptr(v), HOST))
+
+    def set_instance_indices(self, atom_index, rows, cols):
+        a = np.ascontiguousarray(atom_index, dtype=np.int64)
+        r = np.ascontiguousarray(rows, dtype=np.int64)
+        c = np.ascontiguousarray(cols, dtype=np.int64)
+        _check(self._lib.opty_hip_set_instance_indices(
+            self._h, _ptr(a), _ptr(r), _ptr(c)))
+
+    # -- evaluation ------------------------------------------------------------
+    def eval_con(self, free, con, mem):
+        _check(self._lib.opty_hip_eval_con(self._h, _ptr(free), _ptr(con),
+                                           mem))
+
+    def eval_jac(self, free, jac, mem):
+        _check(self._lib.opty_hip_eval_jac(self._h, _ptr(free), _ptr(jac),
+                                           mem))
+
+    def eval_con_jac(self, free, con, jac, mem):
+        _check(self._lib.opty_hip_eval_con_jac(
+            self._h, _ptr(free), _ptr(con), _ptr(jac), mem))
+
+    def jacobian_indices(self, rows, cols, mem):
+        _check(self._lib.opty_hip_jacobian_indices(
+            self._h, _ptr(rows), _ptr(cols), mem))
+
+    def time_eval(self, what, free, con, jac, iters):
+        ms = ctypes.c_float()
+        _check(self._lib.opty_hip_time_eval(
+            self._h, what, _ptr(free), _ptr(con), _ptr(jac), iters,
+            ctypes.byref(ms)))
+        return ms.value

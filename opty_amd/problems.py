@@ -181,8 +181,8 @@ def make_free(num_free, seed=0, variable_duration=False, interval=0.01):
     (h) is set to ``interval``.
     """
     idx = np.arange(num_free, dtype=np.uint64)
-    x = idx + np.uint64(0x9E3779B97F4A7C15)*np.uint64(seed + 1)
     with np.errstate(over='ignore'):
+        x = idx + np.uint64((0x9E3779B97F4A7C15*(seed + 1)) % (1 << 64))
         x ^= x >> np.uint64(30)
         x *= np.uint64(0xBF58476D1CE4E5B9)
         x ^= x >> np.uint64(27)

@@ -1,0 +1,217 @@
+"""CPU tests of the product's host logic and codegen (no GPU, no oracle
+dependency except as the checker): the DAG lowering + forward-mode Jacobian
+evaluated by a test-only NumPy interpreter must reproduce the reference's
+golden vectors; the emitted HIP must build for gfx950; the C-ABI library must
+load and export every symbol of ``include/opty_hip.h``."""
+import ctypes
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+import sympy as sm
+
+import golden_util as gu
+import dag_interp
+from opty_amd import problems, ConstraintCollocator, Problem, parse_free
+from opty_amd import hip_backend as hb
+from opty_amd.codegen import ir
+from opty_amd.codegen.emit_hip import EmitOptions, emit_module
+from opty_amd.codegen.lower import Lowerer, forward_jacobian
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+@pytest.mark.parametrize('name', gu.FULL)
+def test_program_matches_reference(name):
+    meta, z = gu.load(name)
+    col = ConstraintCollocator(**problems.build(name))
+    assert col.num_free == meta['num_free']
+    assert col.num_constraints == meta['num_constraints']
+    assert col.num_block_columns == meta['C']
+    for attr, key in (('state_symbols', 'states'),
+                      ('known_parameters', 'known_parameters'),
+                      ('unknown_parameters', 'unknown_parameters'),
+                      ('known_input_trajectories', 'known_trajectories'),
+                      ('unknown_input_trajectories',
+                       'unknown_trajectories')):
+        assert [str(s) for s in getattr(col, attr)] == meta[key], attr
+    con, jac = dag_interp.evaluate_collocator(col, z['free'])
+    gu.assert_close(con, z['con'], 1e-10, what='con')
+    gu.assert_close(jac, z['jac'], 1e-10, what='jac')
+    r, c = col._instance_constraints_jacobian_indices()
+    if meta['nnz_inst']:
+        np.testing.assert_array_equal(r, z['rows'][-meta['nnz_inst']:])
+        np.testing.assert_array_equal(c, z['cols'][-meta['nnz_inst']:])
+
+
+def test_dag_simplification_and_sharing():
+    d = ir.DAG()
+    x, y = d.input('cur', 0), d.input('cur', 1)
+    assert d.add(x, d.zero) == x and d.mul(x, d.one) == x
+    assert d.mul(x, d.zero) == d.zero and d.sub(x, x) == d.zero
+    assert d.neg(d.neg(x)) == x
+    assert d.add(x, y) == d.add(y, x) and d.mul(x, y) == d.mul(y, x)
+    assert d.add(x, d.neg(y)) == d.sub(x, y)
+    assert d.value(d.mul(d.const(2.0), d.const(3.0))) == 6.0
+    assert d.powi(x, 1) == x and d.powi(x, 0) == d.one
+    assert d.pow(x, d.const(2.0)) == d.powi(x, 2)
+    assert d.unary('cos', d.neg(x)) == d.unary('cos', x)
+    p = d.input('par', 0)
+    assert d.uni[d.mul(p, p)] and not d.uni[d.mul(p, x)]
+
+
+def test_forward_jacobian_against_sympy():
+    """Every derivative rule, against SymPy's own differentiation."""
+    a, b, c = sm.symbols('a b c', real=True)
+    exprs = [sm.sin(a)*sm.cos(b) + sm.tan(c), sm.exp(a*b)/(1 + c**2),
+             sm.sqrt(a**2 + b**2 + 1)*sm.log(c**2 + 2), a**3*b**-2 + c**b,
+             sm.atan2(a, b) + sm.asin(c/3) + sm.acos(c/4) + sm.atan(a*b),
+             sm.sinh(a) + sm.cosh(b)*sm.tanh(c) + sm.Abs(a - b),
+             sm.Max(a, b*c) + sm.Min(a, b)]
+    d = ir.DAG()
+    table = {s: d.input('cur', k) for k, s in enumerate((a, b, c))}
+    low = Lowerer(d, table)
+    outs = [low.lower(e) for e in exprs]
+    jac = forward_jacobian(d, outs, [table[s] for s in (a, b, c)])
+    rng = np.random.default_rng(1)
+    vals = rng.uniform(0.3, 1.7, size=(3, 50))
+    num = dag_interp.evaluate(d, [n for row in jac for n in row],
+                              lambda kind, k: vals[k])
+    sym = sm.Matrix(exprs).jacobian([a, b, c])
+    f = sm.lambdify((a, b, c), sym, 'numpy')
+    for i in range(50):
+        ref = np.array(f(*vals[:, i]), dtype=float).ravel()
+        got = np.array([np.broadcast_to(v, (50,))[i] for v in num])
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-13)
+
+
+def test_parse_free_and_layout():
+    free = np.arange(2*5 + 2*5 + 3 + 1, dtype=float)
+    st, sp, cs, h = parse_free(free, 2, 2, 5, variable_duration=True)
+    assert st.shape == (2, 5) and sp.shape == (2, 5)
+    np.testing.assert_array_equal(cs, [20, 21, 22])
+    assert h == 23
+    st, sp, cs = parse_free(free[:13], 2, 0, 5)
+    assert sp is None and len(cs) == 3
+    st, sp, cs = parse_free(free[:15], 2, 1, 5)
+    assert sp.shape == (5,)
+
+
+def test_api_errors_match_reference_behaviour():
+    kw = problems.mass_spring_damper(num_nodes=5)
+    with pytest.raises(ValueError, match='backend'):
+        ConstraintCollocator(backend='cython', **kw)
+    with pytest.raises(ValueError, match='integration method'):
+        ConstraintCollocator(**dict(kw, integration_method='rk4'))
+    with pytest.raises(ValueError, match='unique'):
+        ConstraintCollocator(**dict(
+            kw, state_symbols=kw['state_symbols'] + kw['state_symbols'][:1]))
+    f = list(kw['known_trajectory_map'])[0]
+    with pytest.raises(ValueError, match='not length'):
+        ConstraintCollocator(**dict(kw, known_trajectory_map={f: np.ones(3)}))
+    # too few states for the derivatives in the equations
+    with pytest.raises(ValueError, match='Too few state'):
+        ConstraintCollocator(**dict(kw,
+                                    state_symbols=kw['state_symbols'][:1]))
+    col = ConstraintCollocator(**kw)
+    assert col.num_states == 2 and col.num_eom == 2
+    assert [s.name for s in col.current_discrete_state_symbols] == ['xi',
+                                                                    'vi']
+    assert [s.name for s in col.previous_discrete_state_symbols] == ['xp',
+                                                                     'vp']
+    assert str(col.time_interval_symbol) == 'h_opty'
+
+
+def test_known_and_unknown_order():
+    """Ordering rules of ``test_known_and_unknown_order``
+    (``opty/tests/test_direct_collocation.py:2042-2088``)."""
+    from sympy.physics.mechanics.models import n_link_pendulum_on_cart
+    import sympy.physics.mechanics as me
+    from opty_amd.utils import sort_sympy
+    me.dynamicsymbols._t = sm.Symbol('t')
+    kane = n_link_pendulum_on_cart(n=3, cart_force=True, joint_torques=True)
+    states = kane.q.col_join(kane.u)
+    eom = kane.mass_matrix_full @ states.diff() - kane.forcing_full
+    g, l0, l1, l2, m0, m1, m2, m3, t = sort_sympy(eom.free_symbols)
+    par_map = {l1: 1.5, l0: 1.0, m3: 2.5, g: 9.81, m1: 1.5}
+    funcs = sort_sympy(f for f in me.find_dynamicsymbols(eom)
+                       if not isinstance(f, sm.Derivative))
+    F, T1, T2, T3 = funcs[:4]
+    N = 51
+    col = ConstraintCollocator(eom, states, N, 0.1,
+                               known_parameter_map=par_map,
+                               known_trajectory_map={T1: np.zeros(N),
+                                                     F: np.ones(N)},
+                               time_symbol=t)
+    assert col.input_trajectories == (T1, F, T2, T3)
+    assert col.known_parameters == (l1, l0, m3, g, m1)
+    assert col.unknown_parameters == (l2, m0, m2)
+    assert col.unknown_input_trajectories == (T2, T3)
+    assert col.num_free == (8 + 2)*N + 3
+
+
+def test_problem_facade_bounds_without_ipopt():
+    """``Problem`` bound arrays (``opty/direct_collocation.py:370-440``) need
+    the device only for the callbacks; check validation that happens first."""
+    kw = problems.mass_spring_damper(num_nodes=5)
+    with pytest.raises(ValueError, match='No time derivatives'):
+        Problem(lambda f: 0.0, lambda f: f, sm.Matrix([sm.Symbol('a')]),
+                kw['state_symbols'], 5, 1.0)
+
+
+def test_emit_builds_for_gfx950(tmp_path):
+    """The printed HIP for the 10-link pendulum cross-compiles for gfx950 with
+    zero scratch (no register spills to memory) in the Jacobian kernels."""
+    if shutil.which('hipcc') is None and not os.path.exists(
+            '/opt/rocm/bin/hipcc'):
+        pytest.skip('hipcc not available')
+    col = ConstraintCollocator(**problems.build('config3_10link_small'))
+    source, meta = col.generate_source()
+    assert meta['P'] == 990 and meta['kernels']['jac']['groups'] >= 1
+    for kern in ('opty_con', 'opty_jac', 'opty_conjac', 'opty_uni'):
+        assert 'void __launch_bounds__(64)\n%s(' % kern in source
+    hsaco = hb.compile_module(source, cache_dir=str(tmp_path))
+    assert os.path.getsize(hsaco) > 0
+    # N does not enter the generated code: one code object serves every N
+    col2 = ConstraintCollocator(**problems.build('config3_10link'))
+    assert col2.generate_source()[1]['sha'] == meta['sha']
+
+
+def test_group_ranges_cover_block():
+    col = ConstraintCollocator(**problems.build('pend3_link_midpoint_small'))
+    prog = col._build_program()
+    for opts in (EmitOptions(), EmitOptions(chunk=8, groups=3),
+                 EmitOptions(chunk=2, groups=100)):
+        _, meta = emit_module(prog, opts)
+        g = meta['groups']
+        assert g[0][0] == 0 and g[-1][1] == prog.P
+        assert all(a[1] == b[0] for a, b in zip(g, g[1:]))
+        assert all(a[0] % 2 == 0 for a in g)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """``libopty_hip.so`` loads (no GPU needed) and exports exactly what
+    ``include/opty_hip.h`` declares; ``create`` fails loudly without a
+    device -- there is no CPU fallback."""
+    header = open(os.path.join(REPO, 'include', 'opty_hip.h')).read()
+    declared = set(re.findall(r'\b(opty_hip_[a-z_]+)\s*\(', header))
+    declared -= {'opty_hip_problem', 'opty_hip_desc'}
+    assert declared == set(hb._SIGNATURES), declared ^ set(hb._SIGNATURES)
+    hb.build_runtime_library()
+    lib = hb.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.opty_hip_device_count() == 0
+        desc = hb._Desc(N=10, n=1, M=1, C=2, jac_groups=1)
+        handle = ctypes.c_void_p()
+        rc = lib.opty_hip_create(ctypes.byref(desc), b'/nonexistent.hsaco',
+                                 ctypes.byref(handle))
+        assert rc != 0
+        assert b'no HIP device' in lib.opty_hip_last_error()
+        col = ConstraintCollocator(**problems.build('msd_be_small'))
+        with pytest.raises(hb.HipBackendError, match='no CPU fallback'):
+            col.generate_constraint_function()

@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP path, called through the C ABI
+(``libopty_hip.so``), against (a) the golden vectors produced by the real
+reference and (b) the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): Jacobian sparsity indices bit-exact, float64
+constraint / Jacobian values within 1e-10 relative.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from opty_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def _collocator(name, **factory_overrides):
+    import opty_amd
+    factory, fkw = problems.CONFIGS[name]
+    return opty_amd.ConstraintCollocator(
+        **factory(**dict(fkw, **factory_overrides)))
+
+
+@pytest.mark.parametrize('name', gu.FULL)
+def test_golden_full(name):
+    """Every value and index of the small reference fixtures."""
+    meta, z = gu.load(name)
+    col = _collocator(name)
+    assert col.num_free == meta['num_free']
+    assert col.num_constraints == meta['num_constraints']
+    con = col.generate_constraint_function()(z['free'])
+    jac = col.generate_jacobian_function()(z['free'])
+    rows, cols = col.jacobian_indices()
+    assert rows.dtype == np.int64 and cols.dtype == np.int64
+    np.testing.assert_array_equal(rows, z['rows'])
+    np.testing.assert_array_equal(cols, z['cols'])
+    gu.assert_close(con, z['con'], RTOL, what=name + ' con')
+    gu.assert_close(jac, z['jac'], RTOL, what=name + ' jac')
+
+
+@pytest.mark.parametrize('name', gu.SAMPLED)
+def test_golden_sampled(name):
+    """BASELINE.json's full sizes (config 2: N=10 000, config 3: N=100 000):
+    strided node samples, per-equation / per-entry sums and tails recorded
+    from the reference."""
+    meta, z = gu.load(name)
+    col = _collocator(name)
+    N, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    free = problems.make_free(col.num_free, seed=meta['seed'],
+                              variable_duration=bool(meta['s']))
+    con = col.generate_constraint_function()(free)
+    jac = col.generate_jacobian_function()(free)
+    rows, cols = col.jacobian_indices()
+    assert len(jac) == meta['nnz'] == len(rows) == len(cols)
+    nodes = z['nodes']
+    blk = jac[:P*(N - 1)].reshape(N - 1, P)
+    cb = con[:M*(N - 1)].reshape(M, N - 1)
+    gu.assert_close(blk[nodes], z['jac_nodes'], RTOL, what='jac nodes')
+    gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL, what='con nodes')
+    np.testing.assert_array_equal(
+        rows[:P*(N - 1)].reshape(N - 1, P)[nodes], z['rows_nodes'])
+    np.testing.assert_array_equal(
+        cols[:P*(N - 1)].reshape(N - 1, P)[nodes], z['cols_nodes'])
+    # order-insensitive checksums over ALL nodes
+    scale = float(z['jac_abs_sum'][0])
+    gu.assert_close(blk.sum(axis=0), z['jac_entry_sums'], 1e-9,
+                    scale=scale/P, what='jac entry sums')
+    gu.assert_close(cb.sum(axis=1), z['con_eq_sums'], 1e-9,
+                    scale=float(np.abs(cb).sum())/M, what='con sums')
+    gu.assert_close(np.abs(blk).sum(), z['jac_abs_sum'][0], 1e-9,
+                    what='jac abs sum')
+    gu.assert_close(con[M*(N - 1):], z['con_tail'], RTOL, what='con tail')
+    gu.assert_close(jac[P*(N - 1):], z['jac_tail'], RTOL, what='jac tail')
+    np.testing.assert_array_equal(rows[P*(N - 1):], z['rows_tail'])
+    np.testing.assert_array_equal(cols[P*(N - 1):], z['cols_tail'])
+
+
+@pytest.mark.parametrize('name,N', [
+    ('config3_10link', 2), ('config3_10link', 3), ('config3_10link', 64),
+    ('config3_10link', 65), ('config3_10link', 66), ('config3_10link', 130),
+    ('config3_10link', 1025),
+    ('pend3_link_midpoint_small', 2), ('pend3_link_midpoint_small', 129),
+    ('vardur_pendulum_small', 70),
+    ('pend2_link_vardur_unkmass_small', 200)])
+def test_against_oracle_ragged(name, N):
+    """Ragged node counts around the 64-node wave (1 constraint node, one
+    short of / exactly / one past a full wave, several waves) vs the oracle."""
+    from oracle.collocation_oracle import OracleCollocator
+    factory, fkw = problems.CONFIGS[name]
+    kw = factory(**dict(fkw, num_nodes=N))
+    import opty_amd
+    col = opty_amd.ConstraintCollocator(**kw)
+    orc = OracleCollocator(name=name.replace('_small', ''), **kw)
+    for seed in (1, 2):
+        free = problems.make_free(col.num_free, seed=seed,
+                                  variable_duration=col._variable_duration)
+        c_ref = orc.generate_constraint_function()(free)
+        j_ref = orc.generate_jacobian_function()(free)
+        gu.assert_close(col.generate_constraint_function()(free), c_ref,
+                        RTOL, what='con')
+        gu.assert_close(col.generate_jacobian_function()(free), j_ref, RTOL,
+                        what='jac')
+    r_ref, k_ref = orc.jacobian_indices()
+    rows, cols = col.jacobian_indices()
+    np.testing.assert_array_equal(rows, r_ref)
+    np.testing.assert_array_equal(cols, k_ref)
+
+
+def test_fused_equals_separate():
+    """opty_hip_eval_con_jac (one launch) == eval_con + eval_jac."""
+    from opty_amd import hip_backend as hb
+    col = _collocator('config3_10link', num_nodes=777)
+    free = problems.make_free(col.num_free, seed=5)
+    con = col.generate_constraint_function()(free)
+    jac = col.generate_jacobian_function()(free).copy()
+    c2 = np.empty_like(con)
+    j2 = np.empty_like(jac)
+    col.hip.eval_con_jac(free, c2, j2, hb.HOST)
+    # same expressions, but the two kernels are scheduled separately, so FMA
+    # contraction may round differently: compare to a few ulps
+    gu.assert_close(j2, jac, 1e-13, what='fused jac')
+    gu.assert_close(c2, con, 1e-13, what='fused con')
+
+
+def test_device_pointers_and_linearity():
+    """Device-resident evaluation through torch tensors on torch's stream;
+    size-independent property at the full N = 100 000: the Jacobian is the
+    derivative of the constraints (directional finite difference)."""
+    import torch
+    from opty_amd import hip_backend as hb
+    col = _collocator('config3_10link')
+    hip = col.hip
+    dev = torch.device('cuda:0')
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    free = problems.make_free(col.num_free, seed=3)
+    rng = np.random.default_rng(0)
+    direction = rng.standard_normal(col.num_free)
+    eps = 1e-6
+    f0 = torch.from_numpy(free).to(dev)
+    fp = torch.from_numpy(free + eps*direction).to(dev)
+    fm = torch.from_numpy(free - eps*direction).to(dev)
+    con_p = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
+    con_m = torch.empty_like(con_p)
+    jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+    rows = torch.empty(hip.nnz, dtype=torch.int64, device=dev)
+    cols = torch.empty(hip.nnz, dtype=torch.int64, device=dev)
+    hip.eval_con(fp, con_p, hb.DEVICE)
+    hip.eval_con(fm, con_m, hb.DEVICE)
+    hip.eval_jac(f0, jac, hb.DEVICE)
+    hip.jacobian_indices(rows, cols, hb.DEVICE)
+    torch.cuda.synchronize()
+    d = torch.from_numpy(direction).to(dev)
+    jv = torch.zeros_like(con_p).index_add_(0, rows, jac*d[cols])
+    fd = (con_p - con_m)/(2*eps)
+    err = (jv - fd).abs().max().item()
+    scale = fd.abs().max().item()
+    assert err <= 1e-6*scale, (err, scale)
+    hip.set_stream(None)
