@@ -38,6 +38,7 @@ from . import ir
 
 WAVE = 64
 TS = 65
+LINE_MODE_MIN_P = 64
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -57,15 +58,25 @@ class EmitOptions(object):
         float64 temporaries of one wave
     """
 
-    def __init__(self, chunk=32, groups=None, max_live=100):
+    def __init__(self, chunk=32, groups=None, max_live=100, ablate=None,
+                 flush_unroll=4):
+        self.flush_unroll = int(flush_unroll)
         self.chunk = int(chunk)
         assert self.chunk % 2 == 0 and self.chunk >= 2
+        # blocks with P >= LINE_MODE_MIN_P use the line-aligned ring flush,
+        # which needs chunk to be a multiple of the 16 doubles of a line
         self.groups = groups
         self.max_live = int(max_live)
+        # profiling aids (never used by the product): 'store_only' writes a
+        # lane-dependent dummy instead of evaluating the expressions,
+        # 'compute_only' predicates every flush store off
+        assert ablate in (None, 'store_only', 'compute_only')
+        self.ablate = ablate
 
     def key(self):
-        return 'chunk=%d groups=%s max_live=%d' % (self.chunk, self.groups,
-                                                   self.max_live)
+        return 'chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d' % (
+            self.chunk, self.groups, self.max_live, self.ablate,
+            self.flush_unroll)
 
 
 def _lit(v):
@@ -301,30 +312,42 @@ class _ModuleWriter(object):
         K = self.o.chunk
         return [(c, min(c + K, e1)) for c in range(e0, e1, K)]
 
+    def line_mode(self):
+        """Line-aligned ring flush (see opty_device.h) for all but tiny
+        blocks; needs the chunk width to be a multiple of a 16-double line."""
+        return self.p.P >= LINE_MODE_MIN_P and self.o.chunk % 16 == 0
+
+    def _virtual_end(self, e1):
+        """Waves evaluate 15 entries past their range so that they own whole
+        lines; the last range wraps into entries 0..14 (of the next node)."""
+        return e1 + 15 if self.line_mode() else e1
+
     def group_ranges(self):
         """Splits the P entries of the block into G contiguous ranges whose
         boundaries are multiples of the chunk width (hence even).  With
         ``groups=None`` the number of groups is the smallest for which every
         group's estimated live temporaries stay below ``max_live``."""
         P, K = self.p.P, self.o.chunk
-        nchunks = (P + K - 1)//K
+        unit = 16 if self.line_mode() else K
+        nunits = max(1, P//unit if self.line_mode() else (P + K - 1)//K)
 
         def split(G):
-            b = [((g*nchunks)//G)*K for g in range(G)] + [P]
+            b = [((g*nunits)//G)*unit for g in range(G)] + [P]
             return [(b[g], b[g + 1]) for g in range(G)]
 
         if self.o.groups is not None:
-            return split(max(1, min(int(self.o.groups), nchunks)))
+            return split(max(1, min(int(self.o.groups), nunits)))
         leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
         G = 1
         while True:
             ranges = split(G)
             worst = max(
                 _max_live(self.dag,
-                          [self.p.jac_out[a:b] for a, b in self._chunks(*rg)],
+                          [[self.p.jac_out[v % P] for v in range(a, b)]
+                           for a, b in self._chunks(e0, self._virtual_end(e1))],
                           leaf)
-                for rg in ranges)
-            if worst <= self.o.max_live or G >= min(nchunks, 16):
+                for e0, e1 in ranges)
+            if worst <= self.o.max_live or G >= min(nunits, 16):
                 return ranges
             G += 1
 
@@ -335,12 +358,18 @@ class _ModuleWriter(object):
         of slab rows)."""
         p, d = self.p, self.dag
         K = self.o.chunk
-        roots = [p.jac_out[e] for e in range(e0, e1)]
+        vend = self._virtual_end(e1) if e1 > e0 else e1
+        roots = [p.jac_out[v % p.P] for v in range(e0, vend)]
         roots += [p.con_out[j] for j in con_rows]
         needed = set(d.reachable(roots))
         rows = sorted({d.args[i][1] for i in needed if self._is_vec_input(i)})
         slab_of = {r: s for s, r in enumerate(rows)}
-        tile_rows = min(K, e1 - e0) if e1 > e0 else 0
+        line_mode = self.line_mode() and e1 > e0
+        R = K + 16
+        if line_mode:
+            tile_rows = R
+        else:
+            tile_rows = min(K, e1 - e0) if e1 > e0 else 0
         slab0 = tile_rows*TS
 
         def leaf(i):
@@ -352,29 +381,79 @@ class _ModuleWriter(object):
                 return 'uni_c[%d]' % self._slot(i)
             return None
 
+        # Slab fill: issue EVERY global load first (65 time nodes per row: one
+        # per lane plus the halo node, which has a wave-uniform address), then
+        # the LDS writes.  Load-by-load (`load; wait; ds_write; branch`) costs
+        # one full memory round trip per row and dominated the wave's life.
         lines = []
-        for r in rows:
-            lines.append('opty_slab_load(lds + %d, %d, %s, node0, N - 1, '
-                         'lane);' % (slab0, slab_of[r], self._row_ptr(r)))
         if rows:
+            lines.append('const long long t_ld = node0 + lane < N - 1 ? '
+                         'node0 + lane : N - 1;')
+            lines.append('const long long t_halo = node0 + 64 < N - 1 ? '
+                         'node0 + 64 : N - 1;')
+        for r in rows:
+            lines.append('const double sl%d = (%s)[t_ld];'
+                         % (r, self._row_ptr(r)))
+            lines.append('const double sh%d = (%s)[t_halo];'
+                         % (r, self._row_ptr(r)))
+        for r in rows:
+            lines.append('lds[%d + lane] = sl%d;'
+                         % (slab0 + slab_of[r]*TS, r))
+        if rows:
+            lines.append('if (lane == 0) {')
+            for r in rows:
+                lines.append('    lds[%d] = sh%d;'
+                             % (slab0 + slab_of[r]*TS + WAVE, r))
+            lines.append('}')
             lines.append('opty_wave_sync();')
         body = _Body(d, needed, leaf)
         for j in con_rows:
             ref = body.emit(p.con_out[j])
             body.lines.append('if (valid) con[%dLL*con_stride + node] = %s;'
                               % (j, ref))
+        nv = '(N < 0 ? nvalid : 0)' if self.o.ablate == 'compute_only' \
+            else 'nvalid'
+
+        def value(e):
+            if self.o.ablate == 'store_only':
+                return '(double)(lane + %d)' % e
+            return body.emit(p.jac_out[e])
+
+        if line_mode:
+            if e1 < p.P:
+                assert e1 + 15 <= p.P, 'last entry range must be >= 16 wide'
+            body.lines.append('const int b0 = opty_line_phase(jrow);')
+            for c0, c1 in self._chunks(e0, e1 + 15):
+                body.new_scope()
+                for v in range(c0, c1):
+                    body.lines.append('lds[%d + lane] = %s;'
+                                      % ((v % R)*TS, value(v % p.P)))
+                body.lines.append('opty_wave_sync();')
+                body.lines.append(
+                    'opty_flush_lines<%d, %d, %d>(lds, jrow, %d, b0, %d, %d, '
+                    '%d, %d, %s, lane);' % ((c1 - c0 + 15)//16, R,
+                                            self.o.flush_unroll, p.P,
+                                            c0 - 15, e0, e1, c1, nv))
+                if e0 == 0 and c0 == 0:
+                    assert c1 >= 15
+                    if self.o.ablate != 'compute_only':
+                        body.lines.append('opty_head_piece<%d>(lds, jrow, '
+                                          '%d, b0, lane);' % (R, p.P))
+                body.lines.append('opty_wave_sync();')
+            return lines + body.lines, tile_rows + len(rows)
+
         wide = (p.P % 2 == 0)
         for c0, c1 in self._chunks(e0, e1):
             body.new_scope()
             for e in range(c0, c1):
-                ref = body.emit(p.jac_out[e])
-                body.lines.append('lds[%d + lane] = %s;' % ((e - c0)*TS, ref))
+                body.lines.append('lds[%d + lane] = %s;'
+                                  % ((e - c0)*TS, value(e)))
             body.lines.append('opty_wave_sync();')
             w = c1 - c0
             fl = 'opty_flush16' if (wide and w % 2 == 0 and c0 % 2 == 0) \
                 else 'opty_flush8'
-            body.lines.append('%s<%d>(lds, jrow + %d, %dLL, nvalid, lane);'
-                              % (fl, w, c0, p.P))
+            body.lines.append('%s<%d>(lds, jrow + %d, %dLL, %s, lane);'
+                              % (fl, w, c0, p.P, nv))
             body.lines.append('opty_wave_sync();')
         return lines + body.lines, tile_rows + len(rows)
 

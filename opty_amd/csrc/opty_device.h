@@ -108,6 +108,99 @@ __device__ __forceinline__ void opty_flush8(const double *tile, double *out,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Line-aligned flush (blocks with P >= 64).
+//
+// Measured on MI355X (tools/store_bench.hip): streaming stores that cover whole
+// 128-byte lines reach ~6.1 TB/s, the same bytes written as 256-byte segments
+// that start at arbitrary 16-byte offsets only ~3.3 TB/s -- every partially
+// written line costs about as much as two full ones.  Node rows are 8*P bytes
+// (7920 for the 10-link pendulum), so row starts drift through all sixteen
+// 8-byte offsets of a line.  The flush therefore works on *lines of the flat
+// output*, not on entries of a node:
+//
+//   * the wave's 64 node rows are one contiguous region; position
+//     L = nd*P + v (node nd, "virtual entry" v); v >= P simply continues into
+//     node nd+1's row;
+//   * the tile is a ring of R >= K+16 entry rows; after a chunk of K entries
+//     every node flushes the (K/16) lines that have just become complete,
+//     wherever their boundaries fall for that node;
+//   * a line is owned by the wave whose entry range holds the line's FIRST
+//     entry; waves evaluate up to 15 entries past their range (the last range
+//     wraps to entries 0..14, which lane nd+1 holds for node nd's last line),
+//     so every line is written exactly once, whole;
+//   * only the two ends of the 64-node block are partial (the line shared with
+//     the neighbouring block): written element-wise by opty_head_piece and by
+//     the straddling-piece branch below.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int opty_line_phase(const double *p) {
+    return (int)((reinterpret_cast<unsigned long long>(p) >> 3) & 15ULL);
+}
+
+typedef unsigned int opty_u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer resource over the wave's output block [jrow, jrow + bytes): raw
+// (stride 0) addressing with hardware range checking -- a store whose byte
+// offset is out of range is dropped, which is how the flush predicates its
+// stores without branching (gfx950 data-format word: 0x00020000).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t
+opty_block_rsrc(double *jrow, int nvalid, int P) {
+    return __builtin_amdgcn_make_buffer_rsrc(
+        jrow, (short)0, nvalid*P*8, 0x00020000);
+}
+
+template <int NL, int R, int UNR>
+__device__ __forceinline__ void opty_flush_lines(const double *tile,
+                                                 double *jrow, int P, int b0,
+                                                 int lo, int own_lo,
+                                                 int own_hi, int avail,
+                                                 int nvalid, int lane) {
+    constexpr int PPN = NL*8;       // 16-byte pieces per node and flush
+    const __amdgpu_buffer_rsrc_t rsrc = opty_block_rsrc(jrow, nvalid, P);
+    // Branch-free: all LDS reads (indices clamped into the tile) and all
+    // stores are issued unconditionally; pieces that must not be written get
+    // an out-of-range buffer offset and are dropped by the hardware.
+    // The loop is only partially unrolled (UNR pieces in flight): fully
+    // unrolled, the flushes dominate the kernel's code size and every wave
+    // streams ~100 KB of once-executed instructions through the I-cache.
+#pragma unroll UNR
+    for (int j = 0; j < PPN; ++j) {
+        const int u = j*OPTY_WAVE + lane;
+        const int nd = u/PPN;
+        const int w = u - nd*PPN;
+        const int o = (b0 + nd*P) & 15;            // line phase of row start
+        const int v0 = lo + ((-(o + lo)) & 15) + 16*(w >> 3);
+        const int v = v0 + 2*(w & 7);
+        const bool ok = nd < nvalid && v0 >= own_lo && v0 < own_hi &&
+                        v0 + 16 <= avail;
+        const int c0 = nd + (v >= P ? 1 : 0);
+        const int c1 = nd + (v + 1 >= P ? 1 : 0);
+        const int vs = v < 0 ? 0 : v;              // keep the reads in range
+        double2 x;
+        x.x = tile[(vs % R)*OPTY_TS + c0];
+        x.y = tile[((vs + 1) % R)*OPTY_TS + c1];
+        const int pos = nd*P + v;
+        const bool full = ok && c1 < nvalid;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            __builtin_bit_cast(opty_u32x4, x), rsrc,
+            full ? pos*8 : 0x7ffffff0, 0, 0);
+        // piece straddling the end of the block's last node (odd line parity
+        // only): its first element alone
+        if (ok && !full && c0 < nvalid) jrow[pos] = x.x;
+    }
+}
+
+// Entries [0, s) of the block's first node share their line with the previous
+// block's last node; nobody else holds them, so the first wave stores them
+// element-wise while entries 0..15 are still in the ring.
+template <int R>
+__device__ __forceinline__ void opty_head_piece(const double *tile,
+                                                double *jrow, int P, int b0,
+                                                int lane) {
+    const int s = (-b0) & 15;
+    if (lane < s && lane < P) jrow[lane] = tile[(lane % R)*OPTY_TS];
+}
+
 template <int N>
 __device__ __forceinline__ double opty_powi(double x) {
     if constexpr (N == 1) return x;

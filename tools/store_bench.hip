@@ -1,0 +1,127 @@
+// Developer micro-benchmark (GPU box): what does the MI355X memory system
+// sustain for the Jacobian's store pattern?  Each 64-lane workgroup owns 64
+// consecutive "nodes" of ROW bytes each and writes them in chunks of SEG bytes
+// per node (what opty_flush16 does), or fully contiguously.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/store_bench.hip -o /tmp/store_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
+    printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// pattern 0: per chunk, lanes cover (64*16/SEG) nodes x SEG bytes per store
+// pattern 1: contiguous 1 KB per store instruction over the block's region
+template <int SEG, bool ALIGN>
+__global__ void __launch_bounds__(64)
+seg_store(double *out, long long row_doubles, long long nnodes, int lds_pad) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long long node0 = (long long)blockIdx.x*64;
+    if (node0 >= nnodes) return;
+    if (lds_pad < 0) lds[lane] = 1.0;           // keep the allocation alive
+    constexpr int LPN = SEG/16;                 // lanes per node
+    constexpr int NPS = 64/LPN;                 // nodes per store
+    const int sub = lane % LPN, nsel = lane/LPN;
+    const long long row_bytes = row_doubles*8;
+    const long long nchunk = row_bytes/SEG;     // whole chunks only
+    char *base = (char *)out + node0*row_bytes;
+    for (long long c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int p = 0; p < 64/NPS; ++p) {
+            const int nd = p*NPS + nsel;
+            if (node0 + nd < nnodes) {
+                long long off = nd*row_bytes + c*SEG + sub*16;
+                if (ALIGN) {
+                    // shift every node's window so that it starts on a
+                    // 128-byte line (what a line-aligned flush would do)
+                    long long start = nd*row_bytes + c*SEG;
+                    long long shift = (128 - ((node0*row_bytes + start) & 127)) & 127;
+                    off += shift;
+                    if (off + 16 > 64*row_bytes) continue;
+                }
+                double2 v = make_double2((double)lane, (double)c);
+                *reinterpret_cast<double2 *>(base + off) = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64)
+contig_store(double *out, long long row_doubles, long long nnodes, int lds_pad) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long long node0 = (long long)blockIdx.x*64;
+    if (node0 >= nnodes) return;
+    if (lds_pad < 0) lds[lane] = 1.0;
+    long long nn = nnodes - node0 < 64 ? nnodes - node0 : 64;
+    const long long bytes = nn*row_doubles*8;
+    char *base = (char *)out + node0*row_doubles*8;
+    for (long long off = lane*16; off + 16 <= bytes; off += 1024) {
+        double2 v = make_double2((double)lane, (double)off);
+        *reinterpret_cast<double2 *>(base + off) = v;
+    }
+}
+
+// plain grid-stride fill, 256-thread blocks (the classic streaming write)
+__global__ void __launch_bounds__(256)
+stream_fill(double2 *out, long long n2) {
+    long long i = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x*blockDim.x;
+    for (; i < n2; i += stride) out[i] = make_double2(1.0, 2.0);
+}
+
+template <typename F>
+float time_ms(F launch, int iters = 20) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch();
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) launch();
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms/iters;
+}
+
+int main() {
+    const long long nnodes = 99999;
+    double *out;
+    const long long max_row = 1024;
+    CHECK(hipMalloc(&out, nnodes*max_row*8 + 4096));
+    const int grid = (int)((nnodes + 63)/64);
+    for (long long row : {990LL, 992LL}) {
+        const double gb = nnodes*row*8/1e9;
+        for (int lds_kb : {0, 16, 28, 40}) {
+            const size_t lds = lds_kb*1024;
+#define RUN(NAME, KERN)                                                       \
+            { float ms = time_ms([&] { hipLaunchKernelGGL(KERN, dim3(grid),   \
+                  dim3(64), lds, 0, out, row, nnodes, 0); });                 \
+              printf("row=%lld lds=%2dKB %-22s %.4f ms  %7.0f GB/s\n", row,   \
+                     lds_kb, NAME, ms, gb/ms*1e3); }
+            RUN("contig", contig_store)
+            RUN("seg128", (seg_store<128, false>))
+            RUN("seg256", (seg_store<256, false>))
+            RUN("seg512", (seg_store<512, false>))
+            RUN("seg1024", (seg_store<1024, false>))
+            RUN("seg256-linealigned", (seg_store<256, true>))
+            RUN("seg512-linealigned", (seg_store<512, true>))
+            fflush(stdout);
+        }
+    }
+    const long long n2 = nnodes*990/2;
+    for (int g : {2048, 8192, 65536}) {
+        float ms = time_ms([&] { hipLaunchKernelGGL(stream_fill, dim3(g),
+                                                    dim3(256), 0, 0,
+                                                    (double2 *)out, n2); });
+        printf("stream_fill grid=%d %.4f ms %7.0f GB/s\n", g, ms,
+               n2*16/1e9/ms*1e3);
+    }
+    float ms = time_ms([&] { CHECK(hipMemsetAsync(out, 0, n2*16, 0)); });
+    printf("hipMemsetAsync %.4f ms %7.0f GB/s\n", ms, n2*16/1e9/ms*1e3);
+    return 0;
+}

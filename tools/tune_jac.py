@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Developer tool (GPU box): time the generated kernels of one workload for a
+sweep of printer options.  Usage:
+
+    python tools/tune_jac.py [workload] "chunk=32,groups=4" "chunk=16" ...
+"""
+import os
+import sys
+import time
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, REPO)
+
+import numpy as np                                            # noqa: E402
+import torch                                                  # noqa: E402
+import opty_amd                                               # noqa: E402
+from opty_amd import problems, hip_backend as hb              # noqa: E402
+from opty_amd.codegen.emit_hip import EmitOptions             # noqa: E402
+
+
+def parse(spec):
+    kw = {}
+    for item in filter(None, spec.split(',')):
+        k, v = item.split('=')
+        kw[k] = None if v == 'None' else (v if k == 'ablate' else int(v))
+    return EmitOptions(**kw)
+
+
+def main():
+    args = sys.argv[1:]
+    workload = 'config3_10link'
+    if args and '=' not in args[0] and args[0] != 'default':
+        workload = args.pop(0)
+    specs = args or ['default']
+    dev = torch.device('cuda:0')
+    kw = problems.build(workload)
+    iters = 30
+    for spec in specs:
+        opts = EmitOptions() if spec == 'default' else parse(spec)
+        t0 = time.time()
+        col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
+        hip = col.hip
+        build_s = time.time() - t0
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        free = torch.from_numpy(problems.make_free(
+            col.num_free, variable_duration=col._variable_duration)).to(dev)
+        con = torch.empty(col.num_constraints, dtype=torch.float64,
+                          device=dev)
+        jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+        res = {}
+        for what, label in ((hb.EVAL_JAC, 'jac'), (hb.EVAL_CON, 'con'),
+                            (hb.EVAL_FUSED, 'fused')):
+            hip.time_eval(what, free, con, jac, 3)
+            res[label] = min(hip.time_eval(what, free, con, jac, iters)
+                             for _ in range(3))
+        prog = col._build_program()
+        nb = 8.0*prog.P*(col.num_collocation_nodes - 1) + 8.0*col.num_free
+        print('%-44s G=%-2d jac %.4f ms (%.0f GB/s, %.1f%% of 8TB/s) '
+              'con %.4f fused %.4f  [build %.0fs]'
+              % (spec, hip.desc['jac_groups'], res['jac'],
+                 nb/res['jac']/1e6, nb/res['jac']/1e6/80.0, res['con'],
+                 res['fused'], build_s), flush=True)
+        hip.close()
+
+
+if __name__ == '__main__':
+    main()
