@@ -83,7 +83,7 @@ def parse_groups(source, kernel='opty_jac'):
         if line.startswith('case ') or cur is None and 'const int b0' in line:
             cur = []
             groups.append(cur)
-        m = re.match(r'lds\[(\d+) \+ lane\] = ', line)
+        m = re.match(r'lds\[(\d+) \+ lane\] = (?!sl\d)', line)
         if m and cur is not None:
             cur.append(('write_slot', int(m.group(1))//TS))
         m = re.match(r'opty_flush_lines<(\d+), (\d+), \d+>\(lds, jrow, (\d+), b0, '
