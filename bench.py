@@ -178,7 +178,8 @@ def main():
                             'outputs left distributed' +
                             (', + RCCL all-gather of con and jac'
                              if gathered is not None else ''),
-                'jac_groups': hip.desc['jac_groups'],
+                'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
+                hip.desc['jac_waves_per_wg'],
                 'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
                 'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
                               'opty_conjac': fused_ms},

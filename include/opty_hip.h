@@ -70,7 +70,9 @@ typedef struct opty_hip_desc {
     int32_t num_inst;     /* o: instance constraints                         */
     int32_t nnz_inst;     /* instance-constraint Jacobian entries            */
     int32_t num_inst_atoms; /* distinct x(t_k) atoms in instance constraints */
-    int32_t jac_groups;   /* waves per 64-node block of opty_jac/opty_conjac */
+    int32_t jac_wgs_per_block; /* workgroups per 64-node block (opty_jac)    */
+    int32_t jac_waves_per_wg;  /* 64-lane waves per such workgroup           */
+    int32_t fused_wgs_per_block; /* workgroups per block of opty_conjac      */
     int32_t num_uniform;  /* entries of the node-invariant table (opty_uni)  */
     int32_t uniform_dynamic; /* 1 if that table depends on `free` (r+s > 0)  */
     int32_t device;       /* HIP device ordinal                              */
@@ -118,6 +120,13 @@ int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
 /* jacobian_indices(): writes nnz int64 rows and cols. */
 int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
                               int64_t *cols, int32_t mem);
+
+/* The same for a handle that evaluates the constraint nodes
+ * [node_offset, node_offset + N - 1) of a larger problem with N_global nodes
+ * (node sharding across GPUs): global row/col indices of the shard's values. */
+int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
+                                    int64_t node_offset, int64_t *rows,
+                                    int64_t *cols, int32_t mem);
 
 /* Runs `iters` evaluations back to back on the handle's stream with device
  * buffers and returns the mean milliseconds per evaluation measured with

@@ -58,11 +58,14 @@ class EmitOptions(object):
         float64 temporaries of one wave
     """
 
-    def __init__(self, chunk=32, groups=None, max_live=100, ablate=None,
-                 flush_unroll=4):
+    def __init__(self, chunk=32, groups=None, max_live=112, ablate=None,
+                 flush_unroll=4, waves=1):
         self.flush_unroll = int(flush_unroll)
+        self.waves = int(waves)      # waves per workgroup (share the slab)
         self.chunk = int(chunk)
         assert self.chunk % 2 == 0 and self.chunk >= 2
+        assert self.chunk < 16 or self.chunk in (16, 32, 64), \
+            'line-mode chunks are 16, 32 or 64 entries'
         # blocks with P >= LINE_MODE_MIN_P use the line-aligned ring flush,
         # which needs chunk to be a multiple of the 16 doubles of a line
         self.groups = groups
@@ -74,9 +77,9 @@ class EmitOptions(object):
         self.ablate = ablate
 
     def key(self):
-        return 'chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d' % (
-            self.chunk, self.groups, self.max_live, self.ablate,
-            self.flush_unroll)
+        return ('chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d '
+                'waves=%d' % (self.chunk, self.groups, self.max_live,
+                              self.ablate, self.flush_unroll, self.waves))
 
 
 def _lit(v):
@@ -105,12 +108,24 @@ class _Body(object):
         self.done = {}
         self.scope = {}
         self.scope_id = 0
+        self.scope_start = 0
+        self.fetches = []
         self.needed = needed
         self.leaf = leaf
 
     def new_scope(self):
+        """Starts a new scope (chunk).  All leaf fetches of the scope that
+        just ended are hoisted to its top so that the scalar loads / LDS reads
+        are issued back to back (and merge into wide s_load instructions)
+        instead of one load + wait in front of every first use."""
+        self.end_scope()
         self.scope = {}
         self.scope_id += 1
+
+    def end_scope(self):
+        self.lines[self.scope_start:self.scope_start] = self.fetches
+        self.fetches = []
+        self.scope_start = len(self.lines)
 
     def ref(self, i):
         d = self.dag
@@ -130,7 +145,7 @@ class _Body(object):
         if src is None:
             return False
         name = 'f%d_%d' % (i, self.scope_id)
-        self.lines.append('const double %s = %s;' % (name, src))
+        self.fetches.append('const double %s = %s;' % (name, src))
         self.scope[i] = name
         return True
 
@@ -338,7 +353,9 @@ class _ModuleWriter(object):
         if self.o.groups is not None:
             return split(max(1, min(int(self.o.groups), nunits)))
         leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
-        G = 1
+        # at least one wave per 256 entries (2 KB of every node row) so that
+        # even an all-constant block yields enough waves to fill the chip
+        G = max(1, min(nunits, (P + 255)//256))
         while True:
             ranges = split(G)
             worst = max(
@@ -352,62 +369,51 @@ class _ModuleWriter(object):
             G += 1
 
     # -- kernels ---------------------------------------------------------------
-    def _group_body(self, e0, e1, con_rows):
+    def _kernel_rows(self, groups, con_of_group):
+        """Trajectory rows any wave of the kernel reads (the shared slab)."""
+        p, d = self.p, self.dag
+        roots = []
+        for (e0, e1), cons in zip(groups, con_of_group):
+            vend = self._virtual_end(e1) if e1 > e0 else e1
+            roots += [p.jac_out[v % p.P] for v in range(e0, vend)]
+            roots += [p.con_out[j] for j in cons]
+        needed = d.reachable(roots)
+        return sorted({d.args[i][1] for i in needed if self._is_vec_input(i)})
+
+    def _ring_rows(self, e0, e1):
+        K = self.o.chunk
+        if e1 <= e0:
+            return 0
+        if self.line_mode():
+            return K + 16
+        return min(K, e1 - e0)
+
+    def _group_body(self, e0, e1, con_rows, slab_of):
         """Code for one wave evaluating Jacobian entries [e0, e1) and the
-        constraint rows ``con_rows`` of its 64 nodes.  Returns (lines, number
-        of slab rows)."""
+        constraint rows ``con_rows`` of its 64 nodes.  Inputs come from the
+        workgroup's shared slab (``lds``), outputs are staged in the wave's
+        private ring tile (``ring``)."""
         p, d = self.p, self.dag
         K = self.o.chunk
         vend = self._virtual_end(e1) if e1 > e0 else e1
         roots = [p.jac_out[v % p.P] for v in range(e0, vend)]
         roots += [p.con_out[j] for j in con_rows]
         needed = set(d.reachable(roots))
-        rows = sorted({d.args[i][1] for i in needed if self._is_vec_input(i)})
-        slab_of = {r: s for s, r in enumerate(rows)}
         line_mode = self.line_mode() and e1 > e0
         R = K + 16
-        if line_mode:
-            tile_rows = R
-        else:
-            tile_rows = min(K, e1 - e0) if e1 > e0 else 0
-        slab0 = tile_rows*TS
 
         def leaf(i):
             if self._is_vec_input(i):
                 kind, r = d.args[i]
                 off = p.cur_offset if kind == 'cur' else p.adj_offset
-                return 'lds[%d + lane + %d]' % (slab0 + slab_of[r]*TS, off)
+                return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
             if self._uniform_leaf(i):
                 return 'uni_c[%d]' % self._slot(i)
             return None
 
-        # Slab fill: issue EVERY global load first (65 time nodes per row: one
-        # per lane plus the halo node, which has a wave-uniform address), then
-        # the LDS writes.  Load-by-load (`load; wait; ds_write; branch`) costs
-        # one full memory round trip per row and dominated the wave's life.
-        lines = []
-        if rows:
-            lines.append('const long long t_ld = node0 + lane < N - 1 ? '
-                         'node0 + lane : N - 1;')
-            lines.append('const long long t_halo = node0 + 64 < N - 1 ? '
-                         'node0 + 64 : N - 1;')
-        for r in rows:
-            lines.append('const double sl%d = (%s)[t_ld];'
-                         % (r, self._row_ptr(r)))
-            lines.append('const double sh%d = (%s)[t_halo];'
-                         % (r, self._row_ptr(r)))
-        for r in rows:
-            lines.append('lds[%d + lane] = sl%d;'
-                         % (slab0 + slab_of[r]*TS, r))
-        if rows:
-            lines.append('if (lane == 0) {')
-            for r in rows:
-                lines.append('    lds[%d] = sh%d;'
-                             % (slab0 + slab_of[r]*TS + WAVE, r))
-            lines.append('}')
-            lines.append('opty_wave_sync();')
         body = _Body(d, needed, leaf)
         for j in con_rows:
+            body.new_scope()      # fetches hoisted per row, not per kernel
             ref = body.emit(p.con_out[j])
             body.lines.append('if (valid) con[%dLL*con_stride + node] = %s;'
                               % (j, ref))
@@ -426,41 +432,95 @@ class _ModuleWriter(object):
             for c0, c1 in self._chunks(e0, e1 + 15):
                 body.new_scope()
                 for v in range(c0, c1):
-                    body.lines.append('lds[%d + lane] = %s;'
+                    body.lines.append('ring[%d + lane] = %s;'
                                       % ((v % R)*TS, value(v % p.P)))
                 body.lines.append('opty_wave_sync();')
+                nlp = 1
+                while 16*nlp < c1 - c0:
+                    nlp *= 2
                 body.lines.append(
-                    'opty_flush_lines<%d, %d, %d>(lds, jrow, %d, b0, %d, %d, '
-                    '%d, %d, %s, lane);' % ((c1 - c0 + 15)//16, R,
-                                            self.o.flush_unroll, p.P,
-                                            c0 - 15, e0, e1, c1, nv))
+                    'opty_flush_lines<%d, %d, %d>(ring, jrow, %d, b0, %d, %d,'
+                    ' %d, %d, %d, %s, lane);' % (
+                        nlp, R, self.o.flush_unroll, p.P, c0 - 15,
+                        (c0 - 15) % R, e0, e1, c1, nv))
                 if e0 == 0 and c0 == 0:
                     assert c1 >= 15
                     if self.o.ablate != 'compute_only':
-                        body.lines.append('opty_head_piece<%d>(lds, jrow, '
+                        body.lines.append('opty_head_piece<%d>(ring, jrow, '
                                           '%d, b0, lane);' % (R, p.P))
                 body.lines.append('opty_wave_sync();')
-            return lines + body.lines, tile_rows + len(rows)
+            body.end_scope()
+            return body.lines
 
         wide = (p.P % 2 == 0)
         for c0, c1 in self._chunks(e0, e1):
             body.new_scope()
             for e in range(c0, c1):
-                body.lines.append('lds[%d + lane] = %s;'
+                body.lines.append('ring[%d + lane] = %s;'
                                   % ((e - c0)*TS, value(e)))
             body.lines.append('opty_wave_sync();')
             w = c1 - c0
             fl = 'opty_flush16' if (wide and w % 2 == 0 and c0 % 2 == 0) \
                 else 'opty_flush8'
-            body.lines.append('%s<%d>(lds, jrow + %d, %dLL, %s, lane);'
+            body.lines.append('%s<%d>(ring, jrow + %d, %dLL, %s, lane);'
                               % (fl, w, c0, p.P, nv))
             body.lines.append('opty_wave_sync();')
-        return lines + body.lines, tile_rows + len(rows)
+        body.end_scope()
+        return body.lines
+
+    def _slab_fill(self, rows, slab_of, W):
+        """Cooperative slab fill: the workgroup's W waves split the rows.  A
+        wave issues EVERY global load of its share first (65 time nodes per
+        row: one per lane plus the halo node, whose address is wave-uniform),
+        then the LDS writes.  Load-by-load (`load; wait; ds_write; branch`)
+        costs one memory round trip per row and dominated the wave's life."""
+        if not rows:
+            return []
+        lines = ['const long long t_ld = node0 + lane < N - 1 ? '
+                 'node0 + lane : N - 1;',
+                 'const long long t_halo = node0 + 64 < N - 1 ? '
+                 'node0 + 64 : N - 1;']
+
+        def share(w):
+            mine = rows[w::W]
+            out = []
+            for r in mine:
+                out.append('const double sl%d = (%s)[t_ld];'
+                           % (r, self._row_ptr(r)))
+                out.append('const double sh%d = (%s)[t_halo];'
+                           % (r, self._row_ptr(r)))
+            for r in mine:
+                out.append('lds[%d + lane] = sl%d;' % (slab_of[r]*TS, r))
+            if mine:
+                out.append('if (lane == 0) {')
+                for r in mine:
+                    out.append('    lds[%d] = sh%d;'
+                               % (slab_of[r]*TS + WAVE, r))
+                out.append('}')
+            return out
+
+        if W == 1:
+            return lines + share(0) + ['opty_wave_sync();']
+        lines.append('switch (wave) {')
+        for w in range(W):
+            lines.append('case %d: {' % w)
+            lines += ['    ' + ln for ln in share(w)]
+            lines.append('} break;')
+        lines.append('default: break;')
+        lines.append('}')
+        lines.append('__syncthreads();')
+        return lines
 
     _PROLOGUE = '''\
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long nblk = (node_end - node_begin + 63)/64;
-    {map}
+    // XCD-aware placement: consecutive workgroup ids round-robin the 8 XCDs;
+    // all workgroups of one 64-node block (same input slab, interleaved
+    // strips of the same output rows) go to the SAME XCD / L2, back to back.
+    const long long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long blk = (slot/{sets})*8 + xcd;
+    const int grp = (int)(slot % {sets})*{W} + wave;
     if (blk >= nblk) return;
     const long long node0 = node_begin + blk*64;
     const long long node = node0 + lane;
@@ -468,33 +528,30 @@ class _ModuleWriter(object):
     const long long rem = node_end - node0;
     const int nvalid = rem < 64 ? (int)rem : 64;
     double *jrow = jac + (node0 - node_begin)*{P}LL;
-    (void)valid; (void)jrow; (void)nvalid; (void)node;
+    double *const ring = lds + {slab} + wave*{ring};
+    (void)valid; (void)jrow; (void)nvalid; (void)node; (void)ring; (void)grp;
 '''
 
-    def kernel(self, name, groups, con_of_group):
-        """One kernel; ``groups`` = list of (e0, e1); ``con_of_group[g]`` =
-        constraint rows stored by group g."""
+    def kernel(self, name, groups, con_of_group, W=1):
+        """One kernel.  ``groups`` = list of entry ranges (e0, e1), one wave
+        each; ``con_of_group[g]`` = constraint rows stored by wave g.  A
+        workgroup is ``W`` consecutive groups of one 64-node block: they share
+        one input slab (filled cooperatively) and each owns a ring tile."""
         G = len(groups)
-        bodies, lds_rows = [], 1
-        for g, (e0, e1) in enumerate(groups):
-            lines, rows = self._group_body(e0, e1, con_of_group[g])
-            bodies.append(lines)
-            lds_rows = max(lds_rows, rows)
-        if G == 1:
-            mapping = 'const long long blk = blockIdx.x; const int grp = 0;'
-        else:
-            # XCD-aware: consecutive workgroup ids round-robin the 8 XCDs, so
-            # give every XCD whole node blocks -- all G waves of a node block
-            # (which write interleaved pieces of the same node rows and read
-            # the same slab) then share one L2.
-            mapping = ('const long long wid = blockIdx.x; '
-                       'const long long xcd = wid & 7, slot = wid >> 3; '
-                       'const long long blk = (slot/%d)*8 + xcd; '
-                       'const int grp = (int)(slot %% %d);' % (G, G))
-        src = ['extern "C" __global__ void __launch_bounds__(64)',
+        W = max(1, min(W, G))
+        sets = (G + W - 1)//W
+        rows = self._kernel_rows(groups, con_of_group)
+        slab_of = {r: k for k, r in enumerate(rows)}
+        ring_rows = max([self._ring_rows(*g) for g in groups] + [0])
+        bodies = [self._group_body(e0, e1, con_of_group[g], slab_of)
+                  for g, (e0, e1) in enumerate(groups)]
+        lds_doubles = max(1, (len(rows) + W*ring_rows)*TS)
+        src = ['extern "C" __global__ void __launch_bounds__(%d)' % (64*W),
                '%s(%s)' % (name, KERNEL_PARAMS), '{',
-               '    __shared__ double lds[%d];' % (lds_rows*TS),
-               self._PROLOGUE.format(map=mapping, P=self.p.P)]
+               '    __shared__ double lds[%d];' % lds_doubles,
+               self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
+                                     slab=len(rows)*TS, ring=ring_rows*TS)]
+        src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
         if G == 1:
             src += ['    ' + ln for ln in bodies[0]]
         else:
@@ -506,8 +563,9 @@ class _ModuleWriter(object):
             src.append('    default: break;')
             src.append('    }')
         src.append('}')
-        return '\n'.join(src), dict(name=name, groups=G,
-                                    lds_bytes=lds_rows*TS*8)
+        return '\n'.join(src), dict(name=name, groups=G, waves_per_wg=W,
+                                    wgs_per_block=sets,
+                                    lds_bytes=lds_doubles*8)
 
     def uniform_kernel(self):
         """Must be printed after every kernel that allocates ``uni`` slots."""
@@ -525,6 +583,7 @@ class _ModuleWriter(object):
         for i, s in slots:
             ref = body.emit(i)
             body.lines.append('uni_w[%d] = %s;' % (s, ref))
+        body.end_scope()
         src = ['extern "C" __global__ void __launch_bounds__(64)',
                'opty_uni(%s)' % KERNEL_PARAMS, '{',
                '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
@@ -553,6 +612,7 @@ class _ModuleWriter(object):
             ref = body.emit(node)
             body.lines.append('if (jac) jac[(node_end - node_begin)*%dLL + '
                               '%d] = %s;' % (p.P, k, ref))
+        body.end_scope()
         src = ['extern "C" __global__ void __launch_bounds__(64)',
                'opty_inst(%s)' % KERNEL_PARAMS, '{',
                '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
@@ -568,21 +628,19 @@ def emit_module(prog, opts=None):
     w = _ModuleWriter(prog, opts)
     groups = w.group_ranges()
     all_rows = list(range(prog.M))
-    # constraint row j is stored by the wave that owns Jacobian row j's first
-    # entry (their temporaries overlap the most)
-    con_of = [[] for _ in groups]
-    for j in all_rows:
-        e = j*prog.C
-        for g, (e0, e1) in enumerate(groups):
-            if e0 <= e < e1:
-                con_of[g].append(j)
+    # The fused kernel is the Jacobian kernel plus one more wave per 64-node
+    # block that evaluates the constraint rows (an empty entry range): the
+    # Jacobian waves keep their register budget, the extra wave rides in the
+    # shadow of the store-bound Jacobian waves.
+    fused_groups = list(groups) + [(0, 0)]
+    con_of = [[] for _ in groups] + [all_rows]
     parts = []
     kernels = {}
-    for key, name, grp, cons in (
-            ('con', 'opty_con', [(0, 0)], [all_rows]),
-            ('jac', 'opty_jac', groups, [[] for _ in groups]),
-            ('conjac', 'opty_conjac', groups, con_of)):
-        src, meta = w.kernel(name, grp, cons)
+    for key, name, grp, cons, wpw in (
+            ('con', 'opty_con', [(0, 0)], [all_rows], 1),
+            ('jac', 'opty_jac', groups, [[] for _ in groups], opts.waves),
+            ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves)):
+        src, meta = w.kernel(name, grp, cons, wpw)
         parts += [src, '']
         kernels[key] = meta
     if prog.inst_con_out:

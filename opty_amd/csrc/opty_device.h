@@ -149,37 +149,50 @@ opty_block_rsrc(double *jrow, int nvalid, int P) {
         jrow, (short)0, nvalid*P*8, 0x00020000);
 }
 
-template <int NL, int R, int UNR>
+// NLP: line slots per node and flush (a power of two >= the lines that can
+// have completed); R: ring rows; UNR: pieces kept in flight.
+// lo = first candidate line start (chunk start - 15), lor = lo mod R (>= 0).
+template <int NLP, int R, int UNR>
 __device__ __forceinline__ void opty_flush_lines(const double *tile,
                                                  double *jrow, int P, int b0,
-                                                 int lo, int own_lo,
+                                                 int lo, int lor, int own_lo,
                                                  int own_hi, int avail,
                                                  int nvalid, int lane) {
-    constexpr int PPN = NL*8;       // 16-byte pieces per node and flush
+    constexpr int PPN = NLP*8;          // 16-byte pieces per node and flush
+    constexpr int NPP = OPTY_WAVE/PPN;  // nodes covered by one pass
+    static_assert((PPN & (PPN - 1)) == 0 && PPN <= OPTY_WAVE, "NLP: 1,2,4,8");
+    static_assert(16*NLP + 16 <= R, "ring too small for the line window");
     const __amdgpu_buffer_rsrc_t rsrc = opty_block_rsrc(jrow, nvalid, P);
-    // Branch-free: all LDS reads (indices clamped into the tile) and all
-    // stores are issued unconditionally; pieces that must not be written get
-    // an out-of-range buffer offset and are dropped by the hardware.
-    // The loop is only partially unrolled (UNR pieces in flight): fully
-    // unrolled, the flushes dominate the kernel's code size and every wave
-    // streams ~100 KB of once-executed instructions through the I-cache.
+    // Lane roles are fixed for the whole flush: which line slot and which
+    // 16-byte piece of it; passes walk over the nodes, so everything that
+    // depends on the node advances by constants.
+    const int w = lane & (PPN - 1);
+    const int k16 = (w >> 3) << 4;
+    const int p2 = (w & 7) << 1;
+    int nd = lane/PPN;
+    int o = (b0 + nd*P) & 15;           // line phase of the node's row start
+    const int dphase = (NPP*P) & 15;
+    int pos0 = nd*P;
+    // Branch-free: all LDS reads (ring slots always in range) and all stores
+    // are issued unconditionally; pieces that must not be written get an
+    // out-of-range buffer offset and are dropped by the hardware.  Partially
+    // unrolled so that UNR pieces are in flight while the code stays small.
 #pragma unroll UNR
     for (int j = 0; j < PPN; ++j) {
-        const int u = j*OPTY_WAVE + lane;
-        const int nd = u/PPN;
-        const int w = u - nd*PPN;
-        const int o = (b0 + nd*P) & 15;            // line phase of row start
-        const int v0 = lo + ((-(o + lo)) & 15) + 16*(w >> 3);
-        const int v = v0 + 2*(w & 7);
+        const int d = ((-(o + lo)) & 15) + k16;     // line start - lo
+        const int v0 = lo + d;
+        const int v = v0 + p2;
         const bool ok = nd < nvalid && v0 >= own_lo && v0 < own_hi &&
                         v0 + 16 <= avail;
+        int r0 = lor + d + p2;                      // < 2R by construction
+        r0 = r0 >= R ? r0 - R : r0;
+        const int r1 = r0 + 1 == R ? 0 : r0 + 1;
         const int c0 = nd + (v >= P ? 1 : 0);
         const int c1 = nd + (v + 1 >= P ? 1 : 0);
-        const int vs = v < 0 ? 0 : v;              // keep the reads in range
         double2 x;
-        x.x = tile[(vs % R)*OPTY_TS + c0];
-        x.y = tile[((vs + 1) % R)*OPTY_TS + c1];
-        const int pos = nd*P + v;
+        x.x = tile[r0*OPTY_TS + c0];
+        x.y = tile[r1*OPTY_TS + c1];
+        const int pos = pos0 + v;
         const bool full = ok && c1 < nvalid;
         __builtin_amdgcn_raw_buffer_store_b128(
             __builtin_bit_cast(opty_u32x4, x), rsrc,
@@ -187,6 +200,9 @@ __device__ __forceinline__ void opty_flush_lines(const double *tile,
         // piece straddling the end of the block's last node (odd line parity
         // only): its first element alone
         if (ok && !full && c0 < nvalid) jrow[pos] = x.x;
+        nd += NPP;
+        o = (o + dphase) & 15;
+        pos0 += NPP*P;
     }
 }
 

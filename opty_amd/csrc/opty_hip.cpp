@@ -63,8 +63,10 @@ struct KernelArgs {
 // pair, 16-byte stores.  Integer, HBM-write bound: 16 bytes per entry.
 // ---------------------------------------------------------------------------
 struct IndexDims {
-    long long N;      // time nodes
-    long long ncon;   // N - 1
+    long long N;      // time nodes of the GLOBAL problem
+    long long ncon;   // N - 1 (global)
+    long long offset; // first global constraint node of this shard
+    long long count;  // constraint nodes of this shard
     int n, q, M, C, tail, method;
 };
 
@@ -97,15 +99,15 @@ opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
     const int P = d.M*d.C;
     const long long i0 = (long long)blockIdx.x*nodes_per_block;
     for (int s = 0; s < nodes_per_block; ++s) {
-        const long long i = i0 + s;
-        if (i >= d.ncon) return;
+        const long long i = i0 + s;           // local constraint node
+        if (i >= d.count) return;
         long long *r = rows + i*P;
         long long *c = cols + i*P;
         for (int e = threadIdx.x; e < P; e += blockDim.x) {
             const int j = e/d.C;
             const int k = e - j*d.C;
             long long row, col;
-            index_of(d, i, j, k, row, col);
+            index_of(d, i + d.offset, j, k, row, col);
             r[e] = row;
             c[e] = col;
         }
@@ -157,8 +159,10 @@ int check_ready(const opty_hip_problem *p) {
     return 0;
 }
 
-int launch(opty_hip_problem *p, hipFunction_t f, int waves_per_block,
-           const double *free_, double *con, double *jac) {
+// wgs_per_block: workgroups per 64-node block (0: a single one-wave launch);
+// threads: workgroup size.
+int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
+           int threads, const double *free_, double *con, double *jac) {
     KernelArgs a;
     a.free_ = free_;
     a.known_traj = p->d_known;
@@ -178,14 +182,14 @@ int launch(opty_hip_problem *p, hipFunction_t f, int waves_per_block,
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
                       HIP_LAUNCH_PARAM_END};
     unsigned grid = 1;
-    if (waves_per_block > 0) {
-        long long nblk = (p->ncon_nodes() + 63)/64;
-        if (waves_per_block > 1)           // XCD-aware mapping pads to 8
-            nblk = ((nblk + 7)/8)*8;
-        grid = (unsigned)(nblk*waves_per_block);
+    if (wgs_per_block > 0) {
+        // node blocks padded to a multiple of the 8 XCDs (see the kernels'
+        // prologue: block -> XCD placement); surplus workgroups exit at once
+        const long long nblk = ((p->ncon_nodes() + 63)/64 + 7)/8*8;
+        grid = (unsigned)(nblk*wgs_per_block);
         if (grid == 0) return 0;
     }
-    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, p->stream,
+    HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, 0, p->stream,
                                   nullptr, config));
     return 0;
 }
@@ -193,23 +197,24 @@ int launch(opty_hip_problem *p, hipFunction_t f, int waves_per_block,
 // what: OPTY_HIP_EVAL_*; device pointers only
 int eval_device(opty_hip_problem *p, int what, const double *free_,
                 double *con, double *jac) {
-    const int G = p->d.jac_groups;
+    const int S = p->d.jac_wgs_per_block, T = 64*p->d.jac_waves_per_wg;
     // Node-invariant sub-expressions: recomputed only when their inputs can
     // have changed (always, if they read unknown parameters / h from `free`).
     if (p->d.num_uniform > 0 && (p->uni_dirty || p->d.uniform_dynamic)) {
-        if (int rc = launch(p, p->k_uni, 0, free_, nullptr, nullptr)) return rc;
+        if (int rc = launch(p, p->k_uni, 0, 64, free_, nullptr, nullptr)) return rc;
         p->uni_dirty = false;
     }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_con, 1, free_, con, nullptr)) return rc;
+        if (int rc = launch(p, p->k_con, 1, 64, free_, con, nullptr)) return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_jac, G, free_, nullptr, jac)) return rc;
+        if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac)) return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
-        if (int rc = launch(p, p->k_conjac, G, free_, con, jac)) return rc;
+        if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block, T, free_, con,
+                            jac)) return rc;
     if (p->d.num_inst > 0) {
         double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr : con;
         double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr : jac;
-        if (int rc = launch(p, p->k_inst, 0, free_, c, j)) return rc;
+        if (int rc = launch(p, p->k_inst, 0, 64, free_, c, j)) return rc;
     }
     return 0;
 }
@@ -269,7 +274,10 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
                     opty_hip_problem **out) {
     if (!desc || !code_object_path || !out) return fail("null argument");
     if (desc->N < 2) return fail("need at least 2 collocation nodes");
-    if (desc->jac_groups < 1) return fail("jac_groups must be >= 1");
+    if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
+        desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1)
+        return fail("bad Jacobian launch geometry (%d workgroups x %d waves)",
+                    desc->jac_wgs_per_block, desc->jac_waves_per_wg);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail("no HIP device is visible: the HIP backend has no CPU "
@@ -441,13 +449,18 @@ int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free_,
     return eval_any(p, OPTY_HIP_EVAL_FUSED, free_, con, jac, mem);
 }
 
-int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
-                              int64_t *cols, int32_t mem) {
-    if (!p) return fail("null handle");
+static int indices_impl(opty_hip_problem *p, int64_t N_global,
+                        int64_t node_offset, int64_t *rows, int64_t *cols,
+                        int32_t mem) {
     if (!rows || !cols) return fail("null buffer");
     if (int rc = use_device(p)) return rc;
     if (p->d.num_inst > 0 && !p->have_inst)
         return fail("instance indices were never set");
+    if (node_offset < 0 || node_offset + p->ncon_nodes() > N_global - 1)
+        return fail("shard [%lld, %lld) outside the %lld constraint nodes",
+                    (long long)node_offset,
+                    (long long)(node_offset + p->ncon_nodes()),
+                    (long long)(N_global - 1));
     long long *dr = (long long *)rows, *dc = (long long *)cols;
     const size_t nnz = (size_t)p->nnz();
     if (mem == OPTY_HIP_HOST) {
@@ -459,8 +472,10 @@ int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
         return fail("bad memory kind %d", mem);
     }
     IndexDims d;
-    d.N = p->d.N;
-    d.ncon = p->ncon_nodes();
+    d.N = N_global;
+    d.ncon = N_global - 1;
+    d.offset = node_offset;
+    d.count = p->ncon_nodes();
     d.n = p->d.n;
     d.q = p->d.q;
     d.M = p->d.M;
@@ -470,7 +485,7 @@ int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
     const int P = (int)p->P();
     // enough entries per block to keep 256 lanes busy
     int npb = P >= 1024 ? 1 : (1024 + P - 1)/P;
-    const unsigned grid = (unsigned)((d.ncon + npb - 1)/npb);
+    const unsigned grid = (unsigned)((d.count + npb - 1)/npb);
     hipLaunchKernelGGL(opty_indices_kernel, dim3(grid), dim3(256), 0,
                        p->stream, d, dr, dc, npb);
     HIP_TRY(hipGetLastError());
@@ -497,6 +512,21 @@ int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
     return 0;
 }
 
+int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
+                              int64_t *cols, int32_t mem) {
+    if (!p) return fail("null handle");
+    return indices_impl(p, p->d.N, 0, rows, cols, mem);
+}
+
+int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
+                                    int64_t node_offset, int64_t *rows,
+                                    int64_t *cols, int32_t mem) {
+    if (!p) return fail("null handle");
+    if (p->d.num_inst > 0)
+        return fail("instance constraints are not node-sharded");
+    return indices_impl(p, N_global, node_offset, rows, cols, mem);
+}
+
 int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
                        double *con, double *jac, int32_t iters,
                        float *ms_per_iter) {
@@ -506,7 +536,7 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
     if (int rc = check_ready(p)) return rc;
     if (p->d.num_uniform > 0 && p->uni_dirty && !p->d.uniform_dynamic) {
         // keep the one-off table fill out of the timed region
-        if (int rc = launch(p, p->k_uni, 0, free_, nullptr, nullptr)) return rc;
+        if (int rc = launch(p, p->k_uni, 0, 64, free_, nullptr, nullptr)) return rc;
         p->uni_dirty = false;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));

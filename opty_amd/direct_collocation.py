@@ -466,7 +466,9 @@ class ConstraintCollocator(object):
             num_inst=self.num_instance_constraints,
             nnz_inst=len(self._inst_rows),
             num_inst_atoms=len(self._inst_atoms),
-            jac_groups=meta['kernels']['jac']['groups'],
+            jac_wgs_per_block=meta['kernels']['jac']['wgs_per_block'],
+            jac_waves_per_wg=meta['kernels']['jac']['waves_per_wg'],
+            fused_wgs_per_block=meta['kernels']['conjac']['wgs_per_block'],
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
             device=self._device)

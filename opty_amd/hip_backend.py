@@ -51,14 +51,14 @@ def build_runtime_library(force=False):
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d)
                 for d in deps)):
         return LIB_PATH
+    tmp = LIB_PATH + '.%d.tmp' % os.getpid()
     cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17',
-           '-Wno-unused-value', '-shared', '-fPIC', src, '-o',
-           LIB_PATH + '.tmp']
+           '-Wno-unused-value', '-shared', '-fPIC', src, '-o', tmp]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise HipBackendError('building libopty_hip.so failed:\n' +
                               proc.stderr)
-    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -83,10 +83,14 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     if os.path.exists(hsaco):
         logger.info('code object cache hit: %s', hsaco)
         return hsaco
-    with open(base + '.hip', 'w') as f:
+    # several ranks may build the same module at once: private temp names,
+    # atomic renames
+    tag = '.%d.tmp' % os.getpid()
+    src_tmp = base + tag + '.hip'
+    with open(src_tmp, 'w') as f:
         f.write(source)
-    cmd = [_hipcc()] + flags + ['--genco', '-I', CSRC, base + '.hip', '-o',
-                                hsaco + '.tmp']
+    cmd = [_hipcc()] + flags + ['--genco', '-I', CSRC, src_tmp, '-o',
+                                hsaco + tag]
     logger.info('compiling %s', base + '.hip')
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if show_compile_output:
@@ -97,9 +101,9 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
         # (opty/utils.py:912-916)
         raise ImportError('Unable to build the HIP code object {}, '
                           'compilation failed. STDERR output from '
-                          'compilation:\n{}'.format(base + '.hip',
-                                                    proc.stderr))
-    os.replace(hsaco + '.tmp', hsaco)
+                          'compilation:\n{}'.format(src_tmp, proc.stderr))
+    os.replace(src_tmp, base + '.hip')
+    os.replace(hsaco + tag, hsaco)
     return hsaco
 
 
@@ -107,7 +111,8 @@ class _Desc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int64)] + [
         (name, ctypes.c_int32) for name in (
             'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'method',
-            'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_groups',
+            'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
+            'jac_waves_per_wg', 'fused_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device')]
 
 
@@ -136,6 +141,8 @@ _SIGNATURES = {
                                              ctypes.c_int32]),
     'opty_hip_jacobian_indices': (ctypes.c_int, [_P, _P, _P,
                                                  ctypes.c_int32]),
+    'opty_hip_jacobian_indices_shard': (ctypes.c_int, [
+        _P, ctypes.c_int64, ctypes.c_int64, _P, _P, ctypes.c_int32]),
     'opty_hip_time_eval': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P,
                                           ctypes.c_int32,
                                           ctypes.POINTER(ctypes.c_float)]),
@@ -257,6 +264,12 @@ class HipProblem(object):
     def jacobian_indices(self, rows, cols, mem):
         _check(self._lib.opty_hip_jacobian_indices(
             self._h, _ptr(rows), _ptr(cols), mem))
+
+    def jacobian_indices_shard(self, num_nodes_global, node_offset, rows,
+                               cols, mem):
+        _check(self._lib.opty_hip_jacobian_indices_shard(
+            self._h, num_nodes_global, node_offset, _ptr(rows), _ptr(cols),
+            mem))
 
     def time_eval(self, what, free, con, jac, iters):
         ms = ctypes.c_float()

@@ -42,13 +42,20 @@ def model_flush(calls, P, b0, nvalid, R):
         else:
             _, NL, lo, own_lo, own_hi, avail = call
             ppn = NL*8
+            npp = 64//ppn
+            lor = lo % R
             for j in range(ppn):
                 for lane in range(64):
-                    u = j*64 + lane
-                    nd, w = divmod(u, ppn)
+                    w = lane & (ppn - 1)
+                    nd = lane//ppn + j*npp
                     o = (b0 + nd*P) & 15
-                    v0 = lo + ((-(o + lo)) & 15) + 16*(w >> 3)
+                    d = ((-(o + lo)) & 15) + ((w >> 3) << 4)
+                    v0 = lo + d
                     v = v0 + 2*(w & 7)
+                    r0 = lor + d + 2*(w & 7)
+                    assert r0 < 2*R
+                    r0 = r0 - R if r0 >= R else r0
+                    assert r0 == v % R
                     ok = (nd < nvalid and own_lo <= v0 < own_hi and
                           v0 + 16 <= avail)
                     c0 = nd + (v >= P)
@@ -83,13 +90,15 @@ def parse_groups(source, kernel='opty_jac'):
         if line.startswith('case ') or cur is None and 'const int b0' in line:
             cur = []
             groups.append(cur)
-        m = re.match(r'lds\[(\d+) \+ lane\] = (?!sl\d)', line)
+        m = re.match(r'ring\[(\d+) \+ lane\] = ', line)
         if m and cur is not None:
             cur.append(('write_slot', int(m.group(1))//TS))
-        m = re.match(r'opty_flush_lines<(\d+), (\d+), \d+>\(lds, jrow, (\d+), b0, '
-                     r'(-?\d+), (\d+), (\d+), (\d+), nvalid, lane\);', line)
+        m = re.match(r'opty_flush_lines<(\d+), (\d+), \d+>\(ring, jrow, (\d+), b0, '
+                     r'(-?\d+), (\d+), (\d+), (\d+), (\d+), nvalid, lane\);',
+                     line)
         if m:
-            NL, R, P, lo, own_lo, own_hi, avail = map(int, m.groups())
+            NL, R, P, lo, lor, own_lo, own_hi, avail = map(int, m.groups())
+            assert lor == lo % R and 16*NL + 16 <= R
             cur.append(('flush', NL, lo, own_lo, own_hi, avail, R, P))
         if line.startswith('opty_head_piece'):
             cur.append(('head',))
@@ -97,7 +106,7 @@ def parse_groups(source, kernel='opty_jac'):
 
 
 @pytest.mark.parametrize('chunk,groups', [(16, None), (32, 1), (32, 3),
-                                          (48, 4), (16, 7)])
+                                          (64, 4), (16, 7)])
 @pytest.mark.parametrize('name', ['config3_10link_small',
                                   'pend3_link_midpoint_small'])
 def test_every_element_written_once(name, chunk, groups):

@@ -159,3 +159,29 @@ def test_device_pointers_and_linearity():
     scale = fd.abs().max().item()
     assert err <= 1e-6*scale, (err, scale)
     hip.set_stream(None)
+
+
+def test_shard_indices_and_values():
+    """A node shard (local N-node problem + halo) reproduces the global
+    problem's slice: values vs the oracle on the global problem, indices from
+    opty_hip_jacobian_indices_shard vs the oracle's global enumeration."""
+    from oracle.collocation_oracle import OracleCollocator
+    from opty_amd.sharded import ShardedCollocator
+    name, N = 'pend3_link_midpoint_small', 301
+    factory, fkw = problems.CONFIGS[name]
+    kw = factory(**dict(fkw, num_nodes=N))
+    orc = OracleCollocator(name='pend3_link_midpoint', **kw)
+    free = problems.make_free(orc.num_free, seed=11)
+    c_ref = orc.generate_constraint_function()(free).reshape(orc.M, N - 1)
+    j_ref = orc.generate_jacobian_function()(free)
+    r_ref, k_ref = orc.jacobian_indices()
+    P = orc.M*orc.C
+    for rank in range(3):
+        sh = ShardedCollocator(rank=rank, world_size=3, **kw)
+        gu.assert_close(sh.constraints_local(free), c_ref[:, sh.a:sh.b],
+                        RTOL, what='con shard')
+        gu.assert_close(sh.jacobian_local(free), j_ref[sh.a*P:sh.b*P], RTOL,
+                        what='jac shard')
+        rows, cols = sh.jacobian_indices_local()
+        np.testing.assert_array_equal(rows, r_ref[sh.a*P:sh.b*P])
+        np.testing.assert_array_equal(cols, k_ref[sh.a*P:sh.b*P])

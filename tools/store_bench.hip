@@ -49,6 +49,44 @@ seg_store(double *out, long long row_doubles, long long nnodes, int lds_pad) {
     }
 }
 
+// pattern 2: like the real kernel -- G waves per 64-node block, each writing
+// a strip of every row in SEG-byte pieces whose boundaries are aligned to
+// ALIGNB bytes (flat address), XCD-aware block placement.
+template <int SEG, int ALIGNB>
+__global__ void __launch_bounds__(64)
+strip_store(double *out, long long row_doubles, long long nnodes, int G) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    if (G < 0) lds[lane] = 1.0;
+    const long long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long blk = (slot/G)*8 + xcd;
+    const int g = (int)(slot % G);
+    const long long node0 = blk*64;
+    if (node0 >= nnodes) return;
+    constexpr int LPN = SEG/16, NPS = 64/LPN;
+    const int sub = lane % LPN, nsel = lane/LPN;
+    const long long row_bytes = row_doubles*8;
+    const long long strip = (row_bytes/G)/SEG*SEG;       // bytes per strip
+    const long long s0 = g*strip, s1 = (g == G - 1) ? row_bytes : s0 + strip;
+    char *base = (char *)out + node0*row_bytes;
+    const long long region = 64*row_bytes;
+    for (long long c = s0; c < s1; c += SEG) {
+#pragma unroll
+        for (int p = 0; p < 64/NPS; ++p) {
+            const int nd = p*NPS + nsel;
+            long long start = nd*row_bytes + c;
+            // first ALIGNB boundary at or after the nominal start
+            long long addr = (long long)base + start;
+            long long al = (addr + ALIGNB - 1)/ALIGNB*ALIGNB - (long long)base;
+            long long off = al + sub*16;
+            if (node0 + nd < nnodes && off + 16 <= region) {
+                double2 v = make_double2((double)lane, (double)c);
+                *reinterpret_cast<double2 *>(base + off) = v;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(64)
 contig_store(double *out, long long row_doubles, long long nnodes, int lds_pad) {
     extern __shared__ double lds[];
@@ -96,7 +134,7 @@ int main() {
     const int grid = (int)((nnodes + 63)/64);
     for (long long row : {990LL, 992LL}) {
         const double gb = nnodes*row*8/1e9;
-        for (int lds_kb : {0, 16, 28, 40}) {
+        for (int lds_kb : {36}) {
             const size_t lds = lds_kb*1024;
 #define RUN(NAME, KERN)                                                       \
             { float ms = time_ms([&] { hipLaunchKernelGGL(KERN, dim3(grid),   \
@@ -111,6 +149,28 @@ int main() {
             RUN("seg256-linealigned", (seg_store<256, true>))
             RUN("seg512-linealigned", (seg_store<512, true>))
             fflush(stdout);
+        }
+    }
+    {
+        const long long row = 990;
+        const double gb = nnodes*row*8/1e9;
+        for (int G : {1, 4, 8}) {
+            const int nblk = (int)(((nnodes + 63)/64 + 7)/8*8);
+            for (int lds_kb : {16, 36}) {
+                const size_t lds = lds_kb*1024;
+#define RUNS(NAME, KERN)                                                      \
+                { float ms = time_ms([&] { hipLaunchKernelGGL(KERN,           \
+                      dim3(nblk*G), dim3(64), lds, 0, out, row, nnodes, G); });\
+                  printf("strips G=%d lds=%2dKB %-14s %.4f ms  %7.0f GB/s\n", \
+                         G, lds_kb, NAME, ms, gb/ms*1e3); }
+                RUNS("seg256/a128", (strip_store<256, 128>))
+                RUNS("seg256/a256", (strip_store<256, 256>))
+                RUNS("seg512/a128", (strip_store<512, 128>))
+                RUNS("seg512/a512", (strip_store<512, 512>))
+                RUNS("seg1024/a128", (strip_store<1024, 128>))
+                RUNS("seg1024/a1024", (strip_store<1024, 1024>))
+                fflush(stdout);
+            }
         }
     }
     const long long n2 = nnodes*990/2;

@@ -57,7 +57,7 @@ def main():
         nb = 8.0*prog.P*(col.num_collocation_nodes - 1) + 8.0*col.num_free
         print('%-44s G=%-2d jac %.4f ms (%.0f GB/s, %.1f%% of 8TB/s) '
               'con %.4f fused %.4f  [build %.0fs]'
-              % (spec, hip.desc['jac_groups'], res['jac'],
+              % (spec, hip.desc['jac_wgs_per_block']*hip.desc['jac_waves_per_wg'], res['jac'],
                  nb/res['jac']/1e6, nb/res['jac']/1e6/80.0, res['con'],
                  res['fused'], build_s), flush=True)
         hip.close()
