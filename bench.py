@@ -8,7 +8,10 @@ metric, ``configs[2]``), inputs resident in HBM.
 One *step* = one ``constraints(free)`` + one ``jacobian(free)`` on a free
 vector that differs from the previous step's (rotating set of synthetic
 vectors already in HBM), evaluated through the C ABI (``libopty_hip.so``) with
-device pointers on torch's current stream.
+device pointers on torch's current stream.  By default both outputs of a step
+come from ONE launch (``opty_hip_eval_con_jac``: the Jacobian waves plus one
+constraint wave per 64-node block); ``--serial`` issues ``opty_hip_eval_con``
+then ``opty_hip_eval_jac`` instead.
 
 Multi-GPU (``--gpus N`` under ``torch.distributed.run``): the collocation
 nodes are sharded, one contiguous node range per rank with a one-node halo
@@ -74,8 +77,9 @@ def main():
     ap.add_argument('--nodes', type=int, default=100000)
     ap.add_argument('--gather', action='store_true',
                     help='all-gather the sharded outputs over RCCL each step')
-    ap.add_argument('--fused', action='store_true',
-                    help='use the single-launch con+jac kernel')
+    ap.add_argument('--serial', action='store_true',
+                    help='two launches per step (opty_hip_eval_con, then '
+                         'opty_hip_eval_jac) instead of opty_hip_eval_con_jac')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -116,11 +120,11 @@ def main():
 
     def step(k):
         f = frees[k % len(frees)]
-        if args.fused:
-            hip.eval_con_jac(f, con, jac, hb.DEVICE)
-        else:
+        if args.serial:
             hip.eval_con(f, con, hb.DEVICE)
             hip.eval_jac(f, jac, hb.DEVICE)
+        else:
+            hip.eval_con_jac(f, con, jac, hb.DEVICE)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered[0], con)
             dist.all_gather_into_tensor(gathered[1], jac)
@@ -158,7 +162,21 @@ def main():
         # `free` once, write the dense blocks once
         jac_bytes = 8.0*nfree + 8.0*P*(N - 1)
         con_bytes = 8.0*nfree + 8.0*M*(N - 1)
-        achieved = jac_bytes/(jac_ms*1e-3)/1e9
+        if args.serial:
+            dom, dom_ms, dom_bytes = 'opty_jac', jac_ms, jac_bytes
+        else:   # one launch reads `free` once and writes both outputs
+            dom, dom_ms = 'opty_conjac', fused_ms
+            dom_bytes = 8.0*nfree + 8.0*M*(N - 1) + 8.0*P*(N - 1)
+        achieved = dom_bytes/(dom_ms*1e-3)/1e9
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+        # collected separately with rocprofv3 as the microarch guide
+        # prescribes; summaries under profiles/)
+        traffic = None
+        try:
+            with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
+                traffic = json.load(f)[dom]['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         value = args.steps*world/elapsed
         out = {
             'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
@@ -172,8 +190,10 @@ def main():
                 'workload': '10-link inverted pendulum on cart, %d nodes per '
                             'GPU, backward Euler, n=M=22, q=1, C=45, nnz=%d '
                             'per GPU' % (N, nnz),
-                'step': ('fused con+jac launch' if args.fused else
-                         'constraints(free) launch + jacobian(free) launch'),
+                'step': ('opty_hip_eval_con + opty_hip_eval_jac (two '
+                         'launches)' if args.serial else
+                         'opty_hip_eval_con_jac (constraints and Jacobian of '
+                         'one free vector from one launch)'),
                 'sharding': 'nodes sharded one contiguous range per GPU, '
                             'outputs left distributed' +
                             (', + RCCL all-gather of con and jac'
@@ -186,9 +206,10 @@ def main():
                 'pair_algorithmic_GB': (jac_bytes + con_bytes)/1e9,
             },
             'roofline': {
-                'bound': 'hbm', 'kernel': 'opty_jac', 'achieved': achieved,
+                'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
+                'algorithmic_bytes_per_launch': dom_bytes,
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved/HBM_PEAK_GBS, 'traffic': None},
+                'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(kw)

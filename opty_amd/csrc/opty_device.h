@@ -139,6 +139,11 @@ __device__ __forceinline__ int opty_line_phase(const double *p) {
 
 typedef unsigned int opty_u32x4 __attribute__((ext_vector_type(4)));
 
+// Cache-policy bits of the flush stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+#ifndef OPTY_STORE_AUX
+#define OPTY_STORE_AUX 0
+#endif
+
 // Buffer resource over the wave's output block [jrow, jrow + bytes): raw
 // (stride 0) addressing with hardware range checking -- a store whose byte
 // offset is out of range is dropped, which is how the flush predicates its
@@ -196,7 +201,7 @@ __device__ __forceinline__ void opty_flush_lines(const double *tile,
         const bool full = ok && c1 < nvalid;
         __builtin_amdgcn_raw_buffer_store_b128(
             __builtin_bit_cast(opty_u32x4, x), rsrc,
-            full ? pos*8 : 0x7ffffff0, 0, 0);
+            full ? pos*8 : 0x7ffffff0, 0, OPTY_STORE_AUX);
         // piece straddling the end of the block's last node (odd line parity
         // only): its first element alone
         if (ok && !full && c0 < nvalid) jrow[pos] = x.x;

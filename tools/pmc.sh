@@ -1,7 +1,7 @@
 #!/bin/bash
 # Developer tool (GPU box): PMC passes over tools/run_jac.py; prints per-kernel sums.
-# usage: tools/pmc.sh "<emit spec>" <outdir>
-SPEC="$1"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$2"; mkdir -p "$OUT"
+# usage: tools/pmc.sh "<emit spec>" <outdir> [jac|con|fused]
+SPEC="$1"; OUT="$GRAFT_REPO_ROOT/gpurun_out/$2"; WHAT="${3:-jac}"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PASSES=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_IFETCH SQ_INSTS_VALU"
@@ -12,7 +12,7 @@ PASSES=(
 )
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --pmc $P -d "$OUT/p$i" -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/run_jac.py "$SPEC" > "$OUT/p$i.log" 2>&1
+  rocprofv3 --pmc $P -d "$OUT/p$i" -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/run_jac.py "$SPEC" $WHAT > "$OUT/p$i.log" 2>&1
   i=$((i+1))
 done
 python - "$OUT" <<'PY'
