@@ -59,7 +59,8 @@ class EmitOptions(object):
     """
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
-                 flush_unroll=4, waves=1, store_aux=18):
+                 flush_unroll=4, waves=1, store_aux=18, con_rows_per_wave=0):
+        self.con_rows_per_wave = int(con_rows_per_wave)
         # cache-policy bits of the flush stores: nt | sc1 -- the Jacobian is
         # written once and never re-read by the kernel; streaming it past the
         # L2 keeps the slab / uni-table reads (and the fused kernel's
@@ -84,9 +85,10 @@ class EmitOptions(object):
 
     def key(self):
         return ('chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d '
-                'waves=%d store_aux=%d' % (
+                'waves=%d store_aux=%d con_rows_per_wave=%d' % (
                     self.chunk, self.groups, self.max_live, self.ablate,
-                    self.flush_unroll, self.waves, self.store_aux))
+                    self.flush_unroll, self.waves, self.store_aux,
+                    self.con_rows_per_wave))
 
 
 def _lit(v):
@@ -371,7 +373,7 @@ class _ModuleWriter(object):
                            for a, b in self._chunks(e0, self._virtual_end(e1))],
                           leaf)
                 for e0, e1 in ranges)
-            if worst <= self.o.max_live or G >= min(nunits, 16):
+            if worst <= self.o.max_live or G >= min(nunits, 32):
                 return ranges
             G += 1
 
@@ -634,17 +636,38 @@ def emit_module(prog, opts=None):
     opts = opts or EmitOptions()
     w = _ModuleWriter(prog, opts)
     groups = w.group_ranges()
-    all_rows = list(range(prog.M))
-    # The fused kernel is the Jacobian kernel plus one more wave per 64-node
-    # block that evaluates the constraint rows (an empty entry range): the
-    # Jacobian waves keep their register budget, the extra wave rides in the
-    # shadow of the store-bound Jacobian waves.
-    fused_groups = list(groups) + [(0, 0)]
-    con_of = [[] for _ in groups] + [all_rows]
+    # Constraint rows may be split over several waves (contiguous row ranges):
+    # one wave evaluating all M defects of a big system runs out of registers.
+    def row_sets(rpw):
+        return [list(range(a, min(a + rpw, prog.M)))
+                for a in range(0, prog.M, rpw)]
+
+    if opts.con_rows_per_wave:
+        con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
+    else:
+        # As few constraint waves as the register budget allows: every wave
+        # re-reads the slab and recomputes the shared sub-expressions, so one
+        # wave for all rows is fastest when it fits (10-link pendulum), while
+        # a 50-equation system needs ~4 rows per wave not to spill.
+        leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
+        parts = 1
+        while True:
+            con_sets = row_sets(-(-prog.M//parts))
+            worst = max(_max_live(prog.dag, [[prog.con_out[j]] for j in rs],
+                                  leaf) for rs in con_sets)
+            if worst <= opts.max_live + 5 or len(con_sets) >= prog.M:
+                break
+            parts += 1
+    con_groups = [(0, 0)]*len(con_sets)
+    # The fused kernel is the Jacobian kernel plus the constraint waves (empty
+    # entry ranges): the Jacobian waves keep their register budget, the extra
+    # waves ride in the shadow of the store-bound Jacobian waves.
+    fused_groups = list(groups) + con_groups
+    con_of = [[] for _ in groups] + con_sets
     parts = []
     kernels = {}
     for key, name, grp, cons, wpw in (
-            ('con', 'opty_con', [(0, 0)], [all_rows], 1),
+            ('con', 'opty_con', con_groups, con_sets, 1),
             ('jac', 'opty_jac', groups, [[] for _ in groups], opts.waves),
             ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves)):
         src, meta = w.kernel(name, grp, cons, wpw)

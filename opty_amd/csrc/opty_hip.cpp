@@ -205,7 +205,8 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
         p->uni_dirty = false;
     }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_con, 1, 64, free_, con, nullptr)) return rc;
+        if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block, 64, free_, con,
+                            nullptr)) return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac)) return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
@@ -275,7 +276,8 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
     if (!desc || !code_object_path || !out) return fail("null argument");
     if (desc->N < 2) return fail("need at least 2 collocation nodes");
     if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
-        desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1)
+        desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1 ||
+        desc->con_wgs_per_block < 1)
         return fail("bad Jacobian launch geometry (%d workgroups x %d waves)",
                     desc->jac_wgs_per_block, desc->jac_waves_per_wg);
     int count = 0;

@@ -469,6 +469,7 @@ class ConstraintCollocator(object):
             jac_wgs_per_block=meta['kernels']['jac']['wgs_per_block'],
             jac_waves_per_wg=meta['kernels']['jac']['waves_per_wg'],
             fused_wgs_per_block=meta['kernels']['conjac']['wgs_per_block'],
+            con_wgs_per_block=meta['kernels']['con']['wgs_per_block'],
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
             device=self._device)

@@ -112,7 +112,7 @@ class _Desc(ctypes.Structure):
         (name, ctypes.c_int32) for name in (
             'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'method',
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
-            'jac_waves_per_wg', 'fused_wgs_per_block',
+            'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device')]
 
 

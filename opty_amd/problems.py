@@ -15,8 +15,8 @@ import sympy as sm
 import sympy.physics.mechanics as me
 
 __all__ = ['vyasarayani', 'pendulum_swing_up', 'n_link_cart_pendulum',
-           'mass_spring_damper', 'variable_duration_pendulum', 'CONFIGS',
-           'make_free']
+           'mass_spring_damper', 'variable_duration_pendulum',
+           'chaplygin_sleigh', 'one_equation', 'CONFIGS', 'make_free']
 
 
 def vyasarayani(num_nodes=51, duration=50.0, method='backward euler'):
@@ -140,6 +140,45 @@ def variable_duration_pendulum(num_nodes=60, method='midpoint'):
                 time_symbol=t, integration_method=method)
 
 
+def chaplygin_sleigh(num_nodes=100, interval=0.1, method='backward euler'):
+    """More equations than states (M = 5, n = 4): the Chaplygin sleigh with
+    one algebraic (nonholonomic) equation, three unknown inputs and eight
+    instance constraints -- ``test_extra_algebraic``
+    (``opty/tests/test_direct_collocation.py:281-345``)."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    m = sm.symbols('m', real=True)
+    x, y, theta = me.dynamicsymbols('x, y, theta', real=True)
+    vx, vy = me.dynamicsymbols('v_x, v_y', real=True)
+    Fx, Fy = me.dynamicsymbols('F_x, F_y')
+    t = me.dynamicsymbols._t
+    eom = sm.Matrix([m*vx.diff() - Fx, x.diff() - vx, m*vy.diff() - Fy,
+                     y.diff() - vy, -sm.sin(theta)*vx + sm.cos(theta)*vy])
+    dur = interval*(num_nodes - 1)
+    inst = (x.func(0.0), y.func(0.0), vx.func(0.0), vy.func(0.0),
+            x.func(dur) - 1.0, y.func(dur) - 1.0, vx.func(dur), vy.func(dur))
+    return dict(equations_of_motion=eom, state_symbols=(x, y, vx, vy),
+                num_collocation_nodes=num_nodes, node_time_interval=interval,
+                known_parameter_map={m: 1.0}, instance_constraints=inst,
+                time_symbol=t, integration_method=method)
+
+
+def one_equation(num_nodes=100, method='backward euler'):
+    """A single equation of motion (M = n = 1, odd block width P = 3) --
+    ``test_one_eom_only``
+    (``opty/tests/test_direct_collocation.py:2337-2393``)."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    y, u = me.dynamicsymbols('y u')
+    eom = sm.Matrix([-y.diff(t) - y**3 + u])
+    t0, tf = 0.0, 10.0
+    inst = (y.func(t0) - 1, y.func(tf) - 1.5)
+    return dict(equations_of_motion=eom, state_symbols=(y,),
+                num_collocation_nodes=num_nodes,
+                node_time_interval=(tf - t0)/(num_nodes - 1),
+                instance_constraints=inst, time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -159,9 +198,18 @@ CONFIGS = {
     'msd_mid_small': (mass_spring_damper, {'num_nodes': 23,
                                            'method': 'midpoint'}),
     'vardur_pendulum_small': (variable_duration_pendulum, {}),
+    'chaplygin_be_small': (chaplygin_sleigh, {}),
+    'chaplygin_mid_small': (chaplygin_sleigh, {'num_nodes': 77,
+                                               'method': 'midpoint'}),
+    'one_eom_be_small': (one_equation, {}),
+    'one_eom_mid_small': (one_equation, {'num_nodes': 67,
+                                         'method': 'midpoint'}),
     'config5_standin_24link': (n_link_cart_pendulum,
                                {'num_links': 24, 'num_nodes': 50000,
                                 'variable_duration': True}),
+    'config5_standin_24link_small': (n_link_cart_pendulum,
+                                     {'num_links': 24, 'num_nodes': 6,
+                                      'variable_duration': True}),
 }
 
 

@@ -42,7 +42,9 @@ OUT = os.path.abspath(os.path.join(HERE, '..'))
 SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'config3_10link_small', 'pend3_link_midpoint_small',
          'pend2_link_vardur_unkmass_small', 'msd_be_small', 'msd_mid_small',
-         'vardur_pendulum_small']
+         'vardur_pendulum_small', 'config5_standin_24link_small',
+         'chaplygin_be_small', 'chaplygin_mid_small', 'one_eom_be_small',
+         'one_eom_mid_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
 
 

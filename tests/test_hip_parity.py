@@ -185,3 +185,46 @@ def test_shard_indices_and_values():
         rows, cols = sh.jacobian_indices_local()
         np.testing.assert_array_equal(rows, r_ref[sh.a*P:sh.b*P])
         np.testing.assert_array_equal(cols, k_ref[sh.a*P:sh.b*P])
+
+
+def test_callable_known_trajectory():
+    """A known trajectory given as a function of ``free``
+    (``opty/direct_collocation.py:2916-2917``): re-evaluated on the host and
+    re-uploaded on every call."""
+    from oracle.collocation_oracle import OracleCollocator
+    import opty_amd
+    kw = problems.mass_spring_damper(num_nodes=150)
+    f = list(kw['known_trajectory_map'])[0]
+    N = kw['num_collocation_nodes']
+    kw['known_trajectory_map'] = {f: lambda free: 0.5*free[:N] + 1.0}
+    col = opty_amd.ConstraintCollocator(**kw)
+    orc = OracleCollocator(name='msd_callable', **kw)
+    con, jac = col.generate_constraint_function(), \
+        col.generate_jacobian_function()
+    for seed in (1, 2):
+        free = problems.make_free(col.num_free, seed=seed)
+        gu.assert_close(con(free), orc.generate_constraint_function()(free),
+                        RTOL, what='con')
+        gu.assert_close(jac(free), orc.generate_jacobian_function()(free),
+                        RTOL, what='jac')
+
+
+def test_parameter_and_interval_updates_refresh_invariants():
+    """The node-invariant table (opty_uni) is recomputed when the known
+    parameters or the interval change on an existing handle."""
+    from oracle.collocation_oracle import OracleCollocator
+    import opty_amd
+    name = 'pend3_link_midpoint_small'
+    factory, fkw = problems.CONFIGS[name]
+    kw = factory(**dict(fkw, num_nodes=90))
+    col = opty_amd.ConstraintCollocator(**kw)
+    free = problems.make_free(col.num_free, seed=4)
+    jac = col.generate_jacobian_function()
+    jac(free)
+    new_map = {k: v*1.25 for k, v in kw['known_parameter_map'].items()}
+    col.hip.set_known_parameters([new_map[p] for p in col.known_parameters])
+    col.hip.set_interval(0.037)
+    kw2 = dict(kw, known_parameter_map=new_map, node_time_interval=0.037)
+    orc = OracleCollocator(name='pend3_link_midpoint', **kw2)
+    gu.assert_close(jac(free), orc.generate_jacobian_function()(free), RTOL,
+                    what='jac after update')

@@ -18,7 +18,7 @@ def _oracle(name):
                             **problems.build(name))
 
 
-@pytest.mark.parametrize('name', gu.FULL)
+@pytest.mark.parametrize('name', gu.FULL_FAST)
 def test_oracle_matches_reference_full(name):
     meta, z = gu.load(name)
     orc = _oracle(name)
