@@ -41,6 +41,7 @@
 #ifndef OPTY_HIP_H
 #define OPTY_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -135,6 +136,12 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
 int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
                        double *con, double *jac, int32_t iters,
                        float *ms_per_iter);
+
+/* Page-locked host memory for OPTY_HIP_HOST callers: output arrays that live
+ * in it (the persistent Jacobian value buffer the reference keeps,
+ * opty/direct_collocation.py:2814) are copied back at full PCIe rate. */
+void *opty_hip_host_alloc(size_t bytes);
+int opty_hip_host_free(void *ptr);
 
 int opty_hip_device_count(void);
 const char *opty_hip_last_error(void);

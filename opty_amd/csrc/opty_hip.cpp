@@ -265,6 +265,22 @@ extern "C" {
 
 const char *opty_hip_last_error(void) { return g_error.c_str(); }
 
+void *opty_hip_host_alloc(size_t bytes) {
+    void *ptr = nullptr;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return ptr;
+}
+
+int opty_hip_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
 int opty_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -551,7 +551,8 @@ class ConstraintCollocator(object):
         (as in the reference, ``:2814``, ``:2887``)."""
         logger.info('Generating jacobian function.')
         hip = self._ensure_hip()
-        result = np.empty(hip.nnz)
+        # page-locked: the (up to GB-sized) copy back runs at PCIe rate
+        result = hb.pinned_empty(hip.nnz)
 
         def jacobian(free):
             free = self._host_free(free)

@@ -146,6 +146,8 @@ _SIGNATURES = {
     'opty_hip_time_eval': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P,
                                           ctypes.c_int32,
                                           ctypes.POINTER(ctypes.c_float)]),
+    'opty_hip_host_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
+    'opty_hip_host_free': (ctypes.c_int, [_P]),
     'opty_hip_device_count': (ctypes.c_int, []),
     'opty_hip_last_error': (ctypes.c_char_p, []),
 }
@@ -189,6 +191,39 @@ def _ptr(x):
     if hasattr(x, 'data_ptr'):
         return x.data_ptr()
     return int(x)
+
+
+class _PinnedBlock(object):
+    """Owner of one ``opty_hip_host_alloc`` block (freed with the last NumPy
+    view of it)."""
+
+    def __init__(self, nbytes):
+        self._lib = load_library()
+        self.ptr = self._lib.opty_hip_host_alloc(nbytes)
+        if not self.ptr:
+            raise HipBackendError(self._lib.opty_hip_last_error().decode())
+        self.nbytes = nbytes
+
+    def __del__(self):
+        if getattr(self, 'ptr', None):
+            self._lib.opty_hip_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_empty(count, dtype=np.float64):
+    """``np.empty(count, dtype)`` in page-locked host memory."""
+    dtype = np.dtype(dtype)
+    block = _PinnedBlock(max(1, count)*dtype.itemsize)
+    buf = (ctypes.c_char*block.nbytes).from_address(block.ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=count)
+    # keep the block alive as long as any view of the array is
+    _PINNED_OWNERS[id(buf)] = block
+    import weakref
+    weakref.finalize(buf, _PINNED_OWNERS.pop, id(buf), None)
+    return arr
+
+
+_PINNED_OWNERS = {}
 
 
 class HipProblem(object):

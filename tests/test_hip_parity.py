@@ -228,3 +228,23 @@ def test_parameter_and_interval_updates_refresh_invariants():
     orc = OracleCollocator(name='pend3_link_midpoint', **kw2)
     gu.assert_close(jac(free), orc.generate_jacobian_function()(free), RTOL,
                     what='jac after update')
+
+
+def test_pinned_host_buffers():
+    """pinned_empty gives ordinary NumPy arrays over page-locked memory and
+    the persistent Jacobian buffer survives its creator going out of scope."""
+    import gc
+    from opty_amd import hip_backend as hb
+    a = hb.pinned_empty(1000)
+    a[:] = np.arange(1000)
+    b = a[10:20]
+    del a
+    gc.collect()
+    np.testing.assert_array_equal(b, np.arange(10, 20))
+    col = _collocator('config3_10link', num_nodes=300)
+    jac = col.generate_jacobian_function()
+    free = problems.make_free(col.num_free, seed=9)
+    first = jac(free).copy()
+    del col
+    gc.collect()
+    np.testing.assert_array_equal(jac(free), first)
