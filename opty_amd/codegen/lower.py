@@ -42,6 +42,11 @@ class Lowerer(object):
             e, ready = stack.pop()
             if e in memo:
                 continue
+            if e in self.sym:
+                # a whole expression bound to an input (e.g. the applied
+                # function r_i(x_i) of an implicit known trajectory)
+                memo[e] = self.sym[e]
+                continue
             if not ready and e.args and not e.is_Number:
                 stack.append((e, True))
                 for a in e.args:
@@ -117,13 +122,16 @@ class Lowerer(object):
         return d.pow(base, exp_node)
 
 
-def forward_jacobian(dag, outputs, wrt_inputs):
+def forward_jacobian(dag, outputs, wrt_inputs, chain=None):
     """Sparse forward-mode Jacobian on the DAG.
 
     ``outputs``: node ids of the M expressions; ``wrt_inputs``: node ids (INPUT
-    nodes) of the C differentiation variables in column order.  Returns an
+    nodes) of the C differentiation variables in column order.  ``chain``:
+    ``{input node: [(wrt input node, derivative node)]}`` for inputs that are
+    themselves known functions of a differentiation variable.  Returns an
     ``M x C`` list of lists of node ids (``dag.zero`` for structural zeros).
     """
+    chain = chain or {}
     d = dag
     col_of = {node: k for k, node in enumerate(wrt_inputs)}
     order = d.reachable(outputs)
@@ -150,6 +158,9 @@ def forward_jacobian(dag, outputs, wrt_inputs):
             g = {}
         elif op == ir.INPUT:
             g = {col_of[i]: d.one} if i in col_of else {}
+            for wrt_node, dnode in chain.get(i, ()):
+                if wrt_node in col_of:
+                    g[col_of[wrt_node]] = dnode
         else:
             a = d.args[i]
             ga = grad[a[0]]

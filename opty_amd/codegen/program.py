@@ -43,7 +43,8 @@ class CollocationProgram(object):
 
 def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
                   num_known_traj, parameters, num_known_par, h_sym,
-                  variable_duration, wrt, method, instance=None):
+                  variable_duration, wrt, method, instance=None,
+                  implicit=()):
     """Lowers the discretised equations and differentiates them.
 
     Parameters mirror the reference's locals: ``state_cur``/``state_adj`` are
@@ -51,6 +52,12 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
     ``traj_cur``/``traj_adj`` the ``si``/``sn`` symbols of *all* m input
     trajectories (known first), ``parameters`` known-then-unknown, ``wrt`` the
     column order of ``opty/direct_collocation.py:2719-2737``.
+
+    ``implicit``: ``[(k, state, kd)]`` -- input trajectory ``k`` is a known
+    function ``r(x_state(t))`` whose derivative ``dr/dx`` is input trajectory
+    ``kd`` (``opty/direct_collocation.py:2080-2093``): its discrete symbol is an
+    applied function ``r_i(x_i)``, lowered as a plain input row that carries a
+    chain-rule link for the Jacobian.
 
     ``instance``: optional ``(expressions, atom_symbols, known_par_syms)`` --
     instance constraints written over one placeholder Symbol per function
@@ -75,10 +82,18 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
         table[s] = dag.input('par', k)
     table[h_sym] = dag.input('h', 0)
 
+    chain = {}
+    for k, st, kd in implicit:
+        chain[dag.input('cur', n + k)] = [(dag.input('cur', st),
+                                           dag.input('cur', n + kd))]
+        if method == 'midpoint':
+            chain[dag.input('adj', n + k)] = [(dag.input('adj', st),
+                                               dag.input('adj', n + kd))]
+
     low = Lowerer(dag, table)
     con_out = [low.lower(e) for e in discrete_eom]
     wrt_nodes = [table[s] for s in wrt]
-    jac = forward_jacobian(dag, con_out, wrt_nodes)
+    jac = forward_jacobian(dag, con_out, wrt_nodes, chain)
     jac_out = [node for row in jac for node in row]
 
     # row r of the slab: states then unknown inputs come from `free`

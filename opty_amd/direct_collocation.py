@@ -254,17 +254,20 @@ class ConstraintCollocator(object):
         if any(isinstance(f, sm.Derivative) for f in non_states):
             raise ValueError('Too few state variables provided for state '
                              'time derivatives found in equations of motion.')
+        # non-state functions may be explicit functions of time, r(t), or
+        # implicit ones through a single state, r(x(t)); the latter need the
+        # user to supply dr/dx as a known trajectory as well
+        # (opty/direct_collocation.py:2009-2018)
+        self._deriv_in_knw_traj = False
         for f in non_states:
             if len(f.args) > 1:
                 raise ValueError(f'{f} is a function of more than one '
                                  'variable.')
             if f.args != (self.time_symbol,):
-                # implicit known trajectories r(x(t)) with chain-rule symbols
-                # (opty/direct_collocation.py:2080-2093, :2284-2302) are a
-                # "next" row of SURVEY.md 8(f), not built yet.
-                raise NotImplementedError(
-                    f'{f}: known trajectories that are functions of a state '
-                    'are not supported by the HIP backend yet.')
+                if f.args[0] not in self.state_symbols:
+                    raise ValueError(f'{f} must be a function of time or of '
+                                     'one state.')
+                self._deriv_in_knw_traj = True
         names = [f.name for f in non_states]
         if len(names) != len(set(names)):
             raise ValueError('Repeated input trajectory variable fnames not '
@@ -295,10 +298,23 @@ class ConstraintCollocator(object):
                                                        'p')
         self._current_discrete_state_symbols = tagged(self.state_symbols, 'i')
         self._next_discrete_state_symbols = tagged(self.state_symbols, 'n')
-        self._current_known_discrete_specified_symbols = tagged(
-            self.known_input_trajectories, 'i')
-        self._next_known_discrete_specified_symbols = tagged(
-            self.known_input_trajectories, 'n')
+        def known(f, tag):
+            # (opty/direct_collocation.py:2080-2093)
+            if isinstance(f, sm.Derivative):          # dr(x(t))/dx(t)
+                var, (wrt, _) = f.args
+                return sm.Symbol('d' + var.__class__.__name__ + tag + '_d' +
+                                 wrt.__class__.__name__ + tag, real=True)
+            if f.args[0] != self.time_symbol:         # r(x(t))
+                arg = sm.Symbol(f.args[0].__class__.__name__ + tag,
+                                real=True)
+                return sm.Function(f.__class__.__name__ + tag,
+                                   real=True)(arg)
+            return sm.Symbol(f.__class__.__name__ + tag, real=True)
+
+        self._current_known_discrete_specified_symbols = tuple(
+            known(f, 'i') for f in self.known_input_trajectories)
+        self._next_known_discrete_specified_symbols = tuple(
+            known(f, 'n') for f in self.known_input_trajectories)
         self._current_unknown_discrete_specified_symbols = tagged(
             self.unknown_input_trajectories, 'i')
         self._next_unknown_discrete_specified_symbols = tagged(
@@ -309,6 +325,44 @@ class ConstraintCollocator(object):
         self._next_discrete_specified_symbols = (
             self._next_known_discrete_specified_symbols +
             self._next_unknown_discrete_specified_symbols)
+
+    def _create_function_replacements(self):
+        """``{r_i(x_i): Symbol('rixi'), d r_i(x_i)/d x_i: Symbol('dri_dxi')}``
+        for every implicit known trajectory, current and next
+        (``opty/direct_collocation.py:2284-2302``).  The HIP backend does not
+        substitute: it lowers ``r_i(x_i)`` as an input row whose derivative
+        with respect to ``x_i`` is the row of ``dri_dxi`` (see
+        ``_implicit_chain``); this method exists for API parity."""
+        repl = {}
+        for f in (self.current_known_discrete_specified_symbols +
+                  self.next_known_discrete_specified_symbols):
+            if isinstance(f, sm.Function) and \
+                    f.args[0] != self.time_symbol:
+                repl[f.diff()] = sm.Symbol(
+                    'd' + f.__class__.__name__ + '_d' + str(f.args[0]),
+                    real=True)
+                repl[f] = sm.Symbol(f.__class__.__name__ + str(f.args[0]),
+                                    real=True)
+        return repl
+
+    def _implicit_chain(self):
+        """``[(index of r in input_trajectories, state index of its argument,
+        index of dr/dx in input_trajectories)]``."""
+        links = []
+        traj = self.input_trajectories
+        for k, f in enumerate(traj):
+            if isinstance(f, sm.Derivative) or \
+                    f.args == (self.time_symbol,):
+                continue
+            arg = f.args[0]
+            deriv = sm.Derivative(f, arg)
+            if deriv not in traj:
+                raise ValueError(
+                    f'{f} is a function of the state {arg}: its derivative '
+                    f'{deriv} must be supplied in known_trajectory_map.')
+            links.append((k, self.state_symbols.index(arg),
+                          traj.index(deriv)))
+        return links
 
     def _discretize_eom(self):
         logger.info('Discretizing the equations of motion.')
@@ -446,7 +500,8 @@ class ConstraintCollocator(object):
             self.num_known_input_trajectories,
             self.parameters, self.num_known_parameters,
             self.time_interval_symbol, self._variable_duration,
-            self._wrt(), self.integration_method, instance)
+            self._wrt(), self.integration_method, instance,
+            implicit=self._implicit_chain())
         return self._program
 
     def generate_source(self):

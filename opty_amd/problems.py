@@ -16,7 +16,8 @@ import sympy.physics.mechanics as me
 
 __all__ = ['vyasarayani', 'pendulum_swing_up', 'n_link_cart_pendulum',
            'mass_spring_damper', 'variable_duration_pendulum',
-           'chaplygin_sleigh', 'one_equation', 'CONFIGS', 'make_free']
+           'chaplygin_sleigh', 'one_equation', 'implicit_known_trajectory',
+           'CONFIGS', 'make_free']
 
 
 def vyasarayani(num_nodes=51, duration=50.0, method='backward euler'):
@@ -179,6 +180,37 @@ def one_equation(num_nodes=100, method='backward euler'):
                 integration_method=method)
 
 
+def implicit_known_trajectory(num_nodes=40, method='backward euler',
+                              variable_duration=True):
+    """Known trajectories that are functions of a state, ``theta(x(t))`` and
+    ``omega(v(t))``, supplied with their derivatives as callables of ``free``
+    -- the system of ``test_implicit_known_traj``
+    (``opty/tests/test_direct_collocation.py:18-70``) with smooth callables
+    so that any N works."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    m, g, r, h = sm.symbols('m, g, r, h', real=True)
+    x, v, f, s = me.dynamicsymbols('x, v, f, s', real=True)
+    t = me.dynamicsymbols._t
+    theta = sm.Function('theta', real=True)(x)
+    omega = sm.Function('omega', real=True)(v)
+    eom = sm.Matrix([x.diff() - v - s + r*omega,
+                     m*v.diff() - f + m*g*sm.sin(theta)])
+    N = num_nodes
+    traj = {
+        omega.diff(v): lambda free: -2.0*free[N:2*N]*np.exp(-free[N:2*N]**2),
+        omega: lambda free: np.exp(-free[N:2*N]**2),
+        s: np.linspace(0.5, 1.5, N),
+        theta: lambda free: 0.3*np.sin(2.0*free[0:N]) + 0.1*free[0:N],
+        theta.diff(x): lambda free: 0.6*np.cos(2.0*free[0:N]) + 0.1,
+    }
+    return dict(equations_of_motion=eom, state_symbols=(x, v),
+                num_collocation_nodes=N,
+                node_time_interval=h if variable_duration else 0.05,
+                known_parameter_map={r: 7.1, m: 3.3, g: 10.2},
+                known_trajectory_map=traj, time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -204,6 +236,10 @@ CONFIGS = {
     'one_eom_be_small': (one_equation, {}),
     'one_eom_mid_small': (one_equation, {'num_nodes': 67,
                                          'method': 'midpoint'}),
+    'implicit_traj_be_small': (implicit_known_trajectory, {}),
+    'implicit_traj_mid_small': (implicit_known_trajectory,
+                                {'num_nodes': 33, 'method': 'midpoint',
+                                 'variable_duration': False}),
     'config5_standin_24link': (n_link_cart_pendulum,
                                {'num_links': 24, 'num_nodes': 50000,
                                 'variable_duration': True}),

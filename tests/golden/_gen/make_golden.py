@@ -44,7 +44,8 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'pend2_link_vardur_unkmass_small', 'msd_be_small', 'msd_mid_small',
          'vardur_pendulum_small', 'config5_standin_24link_small',
          'chaplygin_be_small', 'chaplygin_mid_small', 'one_eom_be_small',
-         'one_eom_mid_small']
+         'one_eom_mid_small', 'implicit_traj_be_small',
+         'implicit_traj_mid_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
 
 

@@ -217,3 +217,39 @@ def test_c_abi_library_exports_every_declared_symbol():
         col = ConstraintCollocator(**problems.build('msd_be_small'))
         with pytest.raises(hb.HipBackendError, match='no CPU fallback'):
             col.generate_constraint_function()
+
+
+def test_implicit_known_trajectories_known_answer():
+    """``test_implicit_known_traj`` of the reference, on the DAG."""
+    import implicit_case
+    kw, free, con_exp, jac_exp, sy = implicit_case.build()
+    col = ConstraintCollocator(**kw)
+    assert col._deriv_in_knw_traj
+    th, om = sy['theta_of_x'], sy['omega_of_v']
+    assert col.known_input_trajectories == (
+        om.diff(sy['v']), om, sy['s'], th, th.diff(sy['x']))
+    assert col.unknown_input_trajectories == (sy['f'],)
+    names = [str(a) for a in col.current_known_discrete_specified_symbols]
+    assert names == ['domegai_dvi', 'omegai(vi)', 'si', 'thetai(xi)',
+                     'dthetai_dxi']
+    repl = col._create_function_replacements()
+    assert sorted(str(v) for v in repl.values()) == sorted(
+        ['dthetai_dxi', 'thetaixi', 'dthetan_dxn', 'thetanxn', 'domegai_dvi',
+         'omegaivi', 'domegan_dvn', 'omeganvn'])
+    con, jac = dag_interp.evaluate_collocator(col, free)
+    np.testing.assert_allclose(con, con_exp)
+    np.testing.assert_allclose(jac, jac_exp)
+    # theta(x, v) and theta(x) + theta(v) are rejected like in the reference
+    x, v = sy['x'], sy['v']
+    bad = sm.Function('theta', real=True)(x, v)
+    eom = sm.Matrix([x.diff() - v, sy['m']*v.diff() + sm.sin(bad)])
+    with pytest.raises(ValueError, match='more than one'):
+        ConstraintCollocator(eom, (x, v), 4, 0.1,
+                             known_trajectory_map={bad: np.zeros(4)},
+                             time_symbol=sy['t'])
+    th_v = sm.Function('theta', real=True)(v)
+    eom = sm.Matrix([x.diff() - v + th_v, sy['m']*v.diff() + sm.sin(th)])
+    with pytest.raises(ValueError, match='Repeated'):
+        ConstraintCollocator(eom, (x, v), 4, 0.1, time_symbol=sy['t'],
+                             known_trajectory_map={th_v: np.zeros(4),
+                                                   th: np.zeros(4)})

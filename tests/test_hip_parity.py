@@ -248,3 +248,16 @@ def test_pinned_host_buffers():
     del col
     gc.collect()
     np.testing.assert_array_equal(jac(free), first)
+
+
+def test_implicit_known_trajectories_known_answer():
+    """The literal arrays of the reference's ``test_implicit_known_traj``
+    through the HIP path."""
+    import implicit_case
+    import opty_amd
+    kw, free, con_exp, jac_exp, _ = implicit_case.build()
+    col = opty_amd.ConstraintCollocator(**kw)
+    np.testing.assert_allclose(col.generate_constraint_function()(free),
+                               con_exp, rtol=1e-12)
+    np.testing.assert_allclose(col.generate_jacobian_function()(free),
+                               jac_exp, rtol=1e-12, atol=1e-14)
