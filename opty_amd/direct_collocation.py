@@ -756,6 +756,67 @@ class Problem(object):
         self.obj_value.append(args[2])
 
     # -- helpers ------------------------------------------------------------
+    def _extraction_map(self):
+        """``{variable: slice of the free vector}`` for every unknown
+        (``opty/direct_collocation.py:972-1002``)."""
+        col = self.collocator
+        N, n = col.num_collocation_nodes, col.num_states
+        q = col.num_unknown_input_trajectories
+        d = {}
+        for k, var in enumerate(col.state_symbols):
+            d[var] = range(k*N, (k + 1)*N)
+        for k, var in enumerate(col.unknown_input_trajectories):
+            d[var] = range((n + k)*N, (n + k + 1)*N)
+        for k, var in enumerate(col.unknown_parameters):
+            d[var] = range((n + q)*N + k, (n + q)*N + k + 1)
+        if col._variable_duration:
+            d[col.time_interval_symbol] = range(self.num_free - 1,
+                                                self.num_free)
+        return d
+
+    def _indices_of(self, variables):
+        d = self._extraction_map()
+        idxs = []
+        for var in variables:
+            try:
+                idxs += list(d[var])
+            except KeyError:
+                raise ValueError(f'{var} not an unknown in this problem.')
+        return idxs
+
+    def fill_free(self, free, values, *variables):
+        """Writes ``values`` into the entries of ``free`` that belong to
+        ``variables`` (``opty/direct_collocation.py:1004-1030``)."""
+        free[self._indices_of(variables)] = values
+
+    def extract_values(self, free, *variables):
+        """The entries of ``free`` that belong to ``variables``
+        (``opty/direct_collocation.py:1032-1054``)."""
+        return free[self._indices_of(variables)]
+
+    def check_bounds_conflict(self, free):
+        """Raises ``ValueError`` if a lower bound exceeds its upper bound or
+        the guess ``free`` violates a bound
+        (``opty/direct_collocation.py:317-368``)."""
+        reversed_bounds = []
+        if self.eom_bounds is not None:
+            reversed_bounds += [k for k, (lo, hi) in self.eom_bounds.items()
+                                if lo > hi]
+        if self.bounds is not None:
+            violating = []
+            for sym, (lo, hi) in self.bounds.items():
+                if np.any(lo > hi):
+                    reversed_bounds.append(sym)
+                vals = self.extract_values(free, sym)
+                if np.any(vals < lo) or np.any(vals > hi):
+                    violating.append(sym)
+            if violating:
+                raise ValueError(f'The initial guesses for {violating} are '
+                                 'in conflict with their bounds.')
+        if reversed_bounds:
+            raise ValueError(f'The lower bound(s) for {reversed_bounds} is '
+                             '(are) greater than the upper bound(s).')
+
     def parse_free(self, free):
         col = self.collocator
         return parse_free(free, col.num_states,
@@ -769,8 +830,14 @@ class Problem(object):
         if col._variable_duration:
             if solution is None:
                 raise ValueError('Solution vector must be provided for '
-                                 'variable duration problems.')
+                                 'variable duration.')
             h = float(solution[-1])
+            if h <= 0.0:
+                raise ValueError('Time interval must be strictly greater '
+                                 'than zero.')
+            if start_time >= h*(N - 1):
+                raise ValueError('Start time must be less than the final '
+                                 'time.')
         else:
             h = col.node_time_interval
         return np.linspace(start_time, start_time + (N - 1)*h, num=N)
@@ -791,5 +858,7 @@ class Problem(object):
     def add_option(self, *args, **kwargs):
         return self._ipopt().add_option(*args, **kwargs)
 
-    def solve(self, free, lagrange=[], zl=[], zu=[]):
+    def solve(self, free, lagrange=[], zl=[], zu=[], respect_bounds=False):
+        if respect_bounds:
+            self.check_bounds_conflict(free)
         return self._ipopt().solve(free, lagrange=lagrange, zl=zl, zu=zu)

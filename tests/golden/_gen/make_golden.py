@@ -116,7 +116,40 @@ def run(name):
     return meta
 
 
+def run_problem_facade():
+    """Bound arrays and extraction helpers of the reference's ``Problem``
+    (``opty/direct_collocation.py:370-440``, ``:972-1054``) for the pendulum
+    swing-up with state / input / eom bounds."""
+    from opty.direct_collocation import Problem
+    kw = problems.pendulum_swing_up(num_nodes=31)
+    theta, omega = kw['state_symbols']
+    T = [f for f in kw['equations_of_motion'].atoms(sm.Function)
+         if f.func.__name__ == 'T'][0]
+    N = kw['num_collocation_nodes']
+    bounds = {T: (-2.0, 2.0), omega: (-np.linspace(1.0, 3.0, N), 10.0)}
+    prob = Problem(lambda f: 0.0, lambda f: f, bounds=bounds,
+                   eom_bounds={1: (-0.5, 0.25)}, **kw)
+    free = problems.make_free(prob.num_free, seed=3)
+    np.savez_compressed(
+        os.path.join(OUT, 'problem_facade.npz'),
+        lower_bound=prob.lower_bound, upper_bound=prob.upper_bound,
+        low_con=prob._low_con_bounds, upp_con=prob._upp_con_bounds,
+        free=free, extract_T_theta=prob.extract_values(free, T, theta),
+        time_vector=prob.time_vector(), INF=np.array([prob.INF]))
+    return dict(kind='facade', name='problem_facade', N=N,
+                num_free=prob.num_free,
+                num_constraints=prob.num_constraints)
+
+
 def main():
+    if sys.argv[1:] == ['problem_facade']:
+        manifest_path = os.path.join(OUT, 'MANIFEST.json')
+        with open(manifest_path) as f:
+            manifest = json.load(f)
+        manifest['problem_facade'] = run_problem_facade()
+        with open(manifest_path, 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     names = sys.argv[1:] or (SMALL + list(LARGE))
     manifest_path = os.path.join(OUT, 'MANIFEST.json')
     manifest = {}

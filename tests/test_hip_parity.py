@@ -261,3 +261,43 @@ def test_implicit_known_trajectories_known_answer():
                                con_exp, rtol=1e-12)
     np.testing.assert_allclose(col.generate_jacobian_function()(free),
                                jac_exp, rtol=1e-12, atol=1e-14)
+
+
+def test_problem_facade_matches_reference():
+    """``Problem``: bound arrays, constraint bounds, extraction helpers and
+    the IPOPT callbacks against arrays recorded from the reference's
+    ``Problem`` (``tests/golden/problem_facade.npz``)."""
+    import os
+    import sympy as sm
+    import opty_amd
+    z = np.load(os.path.join(gu.GOLDEN, 'problem_facade.npz'))
+    kw = problems.pendulum_swing_up(num_nodes=31)
+    theta, omega = kw['state_symbols']
+    T = [f for f in kw['equations_of_motion'].atoms(sm.Function)
+         if f.func.__name__ == 'T'][0]
+    N = kw['num_collocation_nodes']
+    bounds = {T: (-2.0, 2.0), omega: (-np.linspace(1.0, 3.0, N), 10.0)}
+    prob = opty_amd.Problem(lambda f: 0.0, lambda f: f, bounds=bounds,
+                            eom_bounds={1: (-0.5, 0.25)}, **kw)
+    assert prob.INF == z['INF'][0]
+    np.testing.assert_array_equal(prob.lower_bound, z['lower_bound'])
+    np.testing.assert_array_equal(prob.upper_bound, z['upper_bound'])
+    np.testing.assert_array_equal(prob._low_con_bounds, z['low_con'])
+    np.testing.assert_array_equal(prob._upp_con_bounds, z['upp_con'])
+    free = z['free']
+    np.testing.assert_array_equal(prob.extract_values(free, T, theta),
+                                  z['extract_T_theta'])
+    np.testing.assert_allclose(prob.time_vector(), z['time_vector'])
+    rows, cols = prob.jacobianstructure()
+    assert len(rows) == len(prob.jacobian(free)) == 12*(N - 1) + 4
+    assert prob.constraints(free).shape == (prob.num_constraints,)
+    assert prob.objective(free) == 0.0
+    filled = free.copy()
+    prob.fill_free(filled, 1.5, T)
+    assert np.all(prob.extract_values(filled, T) == 1.5)
+    with pytest.raises(ValueError, match='conflict'):
+        prob.check_bounds_conflict(np.full(prob.num_free, 100.0))
+    with pytest.raises(ValueError, match='not an unknown'):
+        prob.extract_values(free, sm.Symbol('nope'))
+    with pytest.raises(ImportError, match='cyipopt'):
+        prob.solve(free)
