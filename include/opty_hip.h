@@ -137,6 +137,30 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
                        double *con, double *jac, int32_t iters,
                        float *ms_per_iter);
 
+/* ---- objective and objective gradient -------------
+ * Device counterpart of create_objective_function (opty/utils.py:329-470):
+ * value = h*sum_i w_i G(node i) + b(p) and its gradient with respect to
+ * free = [x rows, u rows, p], quadrature weights per opty/utils.py:419-464.
+ * The code object exports `opty_objgrad` and `opty_objfin`. */
+typedef struct opty_hip_objective opty_hip_objective;
+
+typedef struct opty_hip_objective_desc {
+    int64_t N;        /* collocation nodes                                   */
+    int32_t n, q, r;  /* states, unknown inputs, unknown parameters          */
+    int32_t device;   /* HIP device ordinal                                  */
+    double h;         /* node time interval                                  */
+} opty_hip_objective_desc;
+
+int opty_hip_objective_create(const opty_hip_objective_desc *desc,
+                              const char *code_object_path,
+                              opty_hip_objective **out);
+int opty_hip_objective_destroy(opty_hip_objective *o);
+int opty_hip_objective_set_stream(opty_hip_objective *o, void *hip_stream);
+/* value: one double (host memory, always); grad: (n+q)*N + r doubles in `mem`
+ * memory or NULL for the value alone; free: (n+q)*N + r doubles in `mem`. */
+int opty_hip_objective_eval(opty_hip_objective *o, const double *free,
+                            double *value, double *grad, int32_t mem);
+
 /* Page-locked host memory for OPTY_HIP_HOST callers: output arrays that live
  * in it (the persistent Jacobian value buffer the reference keeps,
  * opty/direct_collocation.py:2814) are copied back at full PCIe rate. */

@@ -4,6 +4,8 @@ on the hot path)."""
 
 from .direct_collocation import ConstraintCollocator, Problem
 from .utils import parse_free
+from .objective import create_objective_function
 
-__all__ = ['ConstraintCollocator', 'Problem', 'parse_free']
+__all__ = ['ConstraintCollocator', 'Problem', 'parse_free',
+           'create_objective_function']
 __version__ = '0.1.0'

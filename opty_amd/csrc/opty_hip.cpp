@@ -265,6 +265,127 @@ extern "C" {
 
 const char *opty_hip_last_error(void) { return g_error.c_str(); }
 
+// ---------------------------------------------------------------------------
+// objective / objective gradient
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+struct opty_hip_objective {
+    opty_hip_objective_desc d{};
+    hipModule_t module = nullptr;
+    hipFunction_t k_grad = nullptr, k_fin = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    double *d_partial = nullptr, *d_value = nullptr;
+    double *d_free = nullptr, *d_grad = nullptr;   // staging for host callers
+    long long nblk = 0;
+    int64_t num_free() const { return (int64_t)(d.n + d.q)*d.N + d.r; }
+};
+
+extern "C" {
+
+int opty_hip_objective_create(const opty_hip_objective_desc *desc,
+                              const char *code_object_path,
+                              opty_hip_objective **out) {
+    if (!desc || !code_object_path || !out) return fail("null argument");
+    if (desc->N < 2) return fail("need at least 2 collocation nodes");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail("no HIP device is visible: the HIP backend has no CPU "
+                    "fallback");
+    if (desc->device < 0 || desc->device >= count)
+        return fail("device %d out of range (have %d)", desc->device, count);
+    HIP_TRY(hipSetDevice(desc->device));
+    auto *o = new opty_hip_objective;
+    o->d = *desc;
+    hipError_t e = hipModuleLoad(&o->module, code_object_path);
+    if (e != hipSuccess) {
+        delete o;
+        return fail("hipModuleLoad(%s) failed: %s", code_object_path,
+                    hipGetErrorString(e));
+    }
+    if (hipModuleGetFunction(&o->k_grad, o->module, "opty_objgrad") !=
+            hipSuccess ||
+        hipModuleGetFunction(&o->k_fin, o->module, "opty_objfin") !=
+            hipSuccess) {
+        (void)hipModuleUnload(o->module);
+        delete o;
+        return fail("opty_objgrad/opty_objfin missing from %s",
+                    code_object_path);
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&o->own_stream, hipStreamNonBlocking));
+    o->stream = o->own_stream;
+    o->nblk = (desc->N + 63)/64;
+    HIP_TRY(hipMalloc((void **)&o->d_partial,
+                      (size_t)o->nblk*(1 + desc->r)*sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&o->d_value, sizeof(double)));
+    *out = o;
+    return 0;
+}
+
+int opty_hip_objective_destroy(opty_hip_objective *o) {
+    if (!o) return 0;
+    (void)hipSetDevice(o->d.device);
+    (void)hipStreamSynchronize(o->stream);
+    void *bufs[] = {o->d_partial, o->d_value, o->d_free, o->d_grad};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    if (o->own_stream) (void)hipStreamDestroy(o->own_stream);
+    if (o->module) (void)hipModuleUnload(o->module);
+    delete o;
+    return 0;
+}
+
+int opty_hip_objective_set_stream(opty_hip_objective *o, void *hip_stream) {
+    if (!o) return fail("null handle");
+    o->stream = hip_stream ? (hipStream_t)hip_stream : o->own_stream;
+    return 0;
+}
+
+int opty_hip_objective_eval(opty_hip_objective *o, const double *free_,
+                            double *value, double *grad, int32_t mem) {
+    if (!o || !free_ || !value) return fail("null argument");
+    HIP_TRY(hipSetDevice(o->d.device));
+    const double *dfree = free_;
+    double *dgrad = grad;
+    if (mem == OPTY_HIP_HOST) {
+        if (int rc = ensure(&o->d_free, (size_t)o->num_free())) return rc;
+        HIP_TRY(hipMemcpyAsync(o->d_free, free_, o->num_free()*sizeof(double),
+                               hipMemcpyHostToDevice, o->stream));
+        dfree = o->d_free;
+        if (grad) {
+            if (int rc = ensure(&o->d_grad, (size_t)o->num_free())) return rc;
+            dgrad = o->d_grad;
+        }
+    } else if (mem != OPTY_HIP_DEVICE) {
+        return fail("bad memory kind %d", mem);
+    }
+    KernelArgs a{};
+    a.free_ = dfree;
+    a.uni_w = o->d_value;
+    a.con = o->d_partial;
+    a.jac = dgrad;
+    a.h = o->d.h;
+    a.N = o->d.N;
+    a.con_stride = o->nblk;
+    a.node_begin = 0;
+    a.node_end = o->d.N;
+    size_t size = sizeof a;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a,
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                      HIP_LAUNCH_PARAM_END};
+    HIP_TRY(hipModuleLaunchKernel(o->k_grad, (unsigned)o->nblk, 1, 1, 64, 1, 1,
+                                  0, o->stream, nullptr, config));
+    HIP_TRY(hipModuleLaunchKernel(o->k_fin, 1, 1, 1, 64, 1, 1, 0, o->stream,
+                                  nullptr, config));
+    HIP_TRY(hipMemcpyAsync(value, o->d_value, sizeof(double),
+                           hipMemcpyDeviceToHost, o->stream));
+    if (mem == OPTY_HIP_HOST && grad)
+        HIP_TRY(hipMemcpyAsync(grad, o->d_grad, o->num_free()*sizeof(double),
+                               hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return 0;
+}
+
 void *opty_hip_host_alloc(size_t bytes) {
     void *ptr = nullptr;
     if (bytes == 0) bytes = 8;

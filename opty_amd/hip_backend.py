@@ -116,6 +116,12 @@ class _Desc(ctypes.Structure):
             'num_uniform', 'uniform_dynamic', 'device')]
 
 
+class _ObjDesc(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int64), ('n', ctypes.c_int32),
+                ('q', ctypes.c_int32), ('r', ctypes.c_int32),
+                ('device', ctypes.c_int32), ('h', ctypes.c_double)]
+
+
 _lib = None
 
 #: every symbol ``include/opty_hip.h`` declares: (restype, argtypes)
@@ -146,6 +152,13 @@ _SIGNATURES = {
     'opty_hip_time_eval': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P,
                                           ctypes.c_int32,
                                           ctypes.POINTER(ctypes.c_float)]),
+    'opty_hip_objective_create': (ctypes.c_int, [ctypes.POINTER(_ObjDesc),
+                                                 ctypes.c_char_p,
+                                                 ctypes.POINTER(_P)]),
+    'opty_hip_objective_destroy': (ctypes.c_int, [_P]),
+    'opty_hip_objective_set_stream': (ctypes.c_int, [_P, _P]),
+    'opty_hip_objective_eval': (ctypes.c_int, [_P, _P, _P, _P,
+                                               ctypes.c_int32]),
     'opty_hip_host_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
     'opty_hip_host_free': (ctypes.c_int, [_P]),
     'opty_hip_device_count': (ctypes.c_int, []),
@@ -312,3 +325,35 @@ class HipProblem(object):
             self._h, what, _ptr(free), _ptr(con), _ptr(jac), iters,
             ctypes.byref(ms)))
         return ms.value
+
+
+class HipObjective(object):
+    """One ``opty_hip_objective`` handle (objective value + gradient)."""
+
+    def __init__(self, desc, hsaco_path):
+        self._lib = load_library()
+        if self._lib.opty_hip_device_count() == 0:
+            raise HipBackendError('no HIP device is visible: the HIP '
+                                  'backend has no CPU fallback')
+        self._h = _P()
+        d = _ObjDesc(**desc)
+        _check(self._lib.opty_hip_objective_create(
+            ctypes.byref(d), hsaco_path.encode(), ctypes.byref(self._h)))
+        self.desc = dict(desc)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.opty_hip_objective_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib.opty_hip_objective_set_stream(self._h, stream_ptr))
+
+    def evaluate(self, free, grad, mem):
+        """Returns the objective value; fills ``grad`` when it is given."""
+        value = ctypes.c_double()
+        _check(self._lib.opty_hip_objective_eval(
+            self._h, _ptr(free), ctypes.addressof(value), _ptr(grad), mem))
+        return value.value

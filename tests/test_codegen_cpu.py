@@ -253,3 +253,77 @@ def test_implicit_known_trajectories_known_answer():
         ConstraintCollocator(eom, (x, v), 4, 0.1, time_symbol=sy['t'],
                              known_trajectory_map={th_v: np.zeros(4),
                                                    th: np.zeros(4)})
+
+
+def _interp_objective(case, t):
+    """Objective value and gradient from the objective DAG, with the
+    quadrature rules applied on the host (test-only)."""
+    from opty_amd.objective import build_objective_program
+    states, inputs, unknowns = case['args']
+    dag, roots, n, q, r = build_objective_program(
+        case['expr'], states, inputs, unknowns, case['method'], t)
+    g_quad, dp_quad, dz_node, b_val, db_val = roots
+    free, h = case['free'], case['h']
+    N = (len(free) - r)//(n + q)
+    rows = free[:(n + q)*N].reshape(n + q, N)
+    par = free[(n + q)*N:]
+
+    def inputs_at(cur_idx, adj_idx):
+        def f(kind, k):
+            if kind == 'cur':
+                return rows[k, cur_idx]
+            if kind == 'adj':
+                return rows[k, adj_idx]
+            return par[k]
+        return f
+
+    nodes = np.arange(N)
+    ones = np.ones(N)
+    dz = dag_interp.evaluate(dag, dz_node, inputs_at(nodes, nodes))
+    if case['method'] == 'backward euler':
+        wq = np.hstack((0, np.ones(N - 1)))
+        wg = wq
+        quad = dag_interp.evaluate(dag, [g_quad] + dp_quad,
+                                   inputs_at(nodes, nodes))
+        sums = [float(np.sum(np.atleast_1d(v)*ones*wq)) for v in quad]
+    else:
+        wg = np.hstack((0.5, np.ones(N - 2), 0.5))
+        quad = dag_interp.evaluate(dag, [g_quad] + dp_quad,
+                                   inputs_at(nodes[:-1], nodes[1:]))
+        sums = [float(np.sum(np.atleast_1d(v)*np.ones(N - 1))) for v in quad]
+    bb = dag_interp.evaluate(dag, [b_val] + db_val, inputs_at(0, 0))
+    value = h*sums[0] + float(bb[0])
+    grad = np.hstack([h*wg*np.atleast_1d(v)*ones for v in dz] +
+                     [np.array([h*sums[1 + k] + float(bb[1 + k])
+                                for k in range(r)])])
+    return value, grad
+
+
+def test_objective_program_known_answers():
+    """``TestCreateObjectiveFunction`` of the reference
+    (``opty/tests/test_utils.py:67-219``) on the objective DAG."""
+    import objective_cases
+    t, cases = objective_cases.cases()
+    for case in cases:
+        value, grad = _interp_objective(case, t)
+        np.testing.assert_allclose(value, case['value'], rtol=1e-12,
+                                   err_msg=case['name'])
+        np.testing.assert_allclose(grad, case['grad'], rtol=1e-12,
+                                   atol=1e-15, err_msg=case['name'])
+
+
+def test_objective_rejections():
+    from opty_amd.objective import build_objective_program
+    t = sm.symbols('t')
+    x = sm.Function('x')(t)
+    with pytest.raises(NotImplementedError):
+        build_objective_program(sm.Integral(x**2, t), [x], [], [],
+                                'not_existing_method', t)
+    with pytest.raises(NotImplementedError):
+        build_objective_program(sm.Integral(x**2, (t, 0, 1)), [x], [], [],
+                                'backward euler', t)
+    with pytest.raises(NotImplementedError):
+        build_objective_program(sm.Integral(x**2, t)**2, [x], [], [],
+                                'backward euler', t)
+    with pytest.raises(NotImplementedError):
+        build_objective_program(x**2, [x], [], [], 'backward euler', t)
