@@ -67,6 +67,8 @@ typedef struct opty_hip_desc {
     int32_t r;            /* unknown parameters                              */
     int32_t s;            /* 1 if the node time interval is free             */
     int32_t C;            /* columns of the per-node block (len(wrt))        */
+    int32_t P;            /* values stored per node: M*C (the reference's dense
+                             block), fewer when structural zeros are pruned  */
     int32_t method;       /* OPTY_HIP_BACKWARD_EULER / OPTY_HIP_MIDPOINT     */
     int32_t num_inst;     /* o: instance constraints                         */
     int32_t nnz_inst;     /* instance-constraint Jacobian entries            */
@@ -105,6 +107,9 @@ int opty_hip_set_known_trajectories(opty_hip_problem *p, const double *values,
 int opty_hip_set_instance_indices(opty_hip_problem *p,
                                   const int64_t *atom_free_index,
                                   const int64_t *rows, const int64_t *cols);
+
+/* Pruned blocks only (P < M*C): (j, k) of every stored entry, 2*P int32. */
+int opty_hip_set_block_pattern(opty_hip_problem *p, const int32_t *jk);
 
 int64_t opty_hip_num_free(const opty_hip_problem *p);
 int64_t opty_hip_num_constraints(const opty_hip_problem *p);

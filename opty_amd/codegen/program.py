@@ -38,13 +38,15 @@ class CollocationProgram(object):
 
     @property
     def P(self):
-        return self.M*self.C
+        """Values stored per constraint node: M*C for the reference's dense
+        block, fewer when structural zeros are pruned."""
+        return len(self.jac_out)
 
 
 def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
                   num_known_traj, parameters, num_known_par, h_sym,
                   variable_duration, wrt, method, instance=None,
-                  implicit=()):
+                  implicit=(), prune_zeros=False):
     """Lowers the discretised equations and differentiates them.
 
     Parameters mirror the reference's locals: ``state_cur``/``state_adj`` are
@@ -94,7 +96,14 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
     con_out = [low.lower(e) for e in discrete_eom]
     wrt_nodes = [table[s] for s in wrt]
     jac = forward_jacobian(dag, con_out, wrt_nodes, chain)
-    jac_out = [node for row in jac for node in row]
+    # (j, k) of every stored entry of the block, row-major.  The reference
+    # stores all M*C of them, structural zeros included
+    # (opty/direct_collocation.py:2589-2593); ``prune_zeros`` (opt-in, changes
+    # the index contract) keeps only entries whose partial is not identically
+    # zero.
+    pattern = [(j, k) for j, row in enumerate(jac) for k, node in
+               enumerate(row) if not (prune_zeros and node == dag.zero)]
+    jac_out = [jac[j][k] for j, k in pattern]
 
     # row r of the slab: states then unknown inputs come from `free`
     # (``free`` viewed as (n+q, N), opty/utils.py:308-318); known inputs from
@@ -129,4 +138,5 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
         cur_offset=1 if method == 'backward euler' else 0,
         adj_offset=0 if method == 'backward euler' else 1,
         inst_con_out=inst_con_out, inst_jac_out=inst_jac_out,
-        num_inst_atoms=num_atoms)
+        num_inst_atoms=num_atoms, pattern=pattern,
+        pruned=bool(prune_zeros))

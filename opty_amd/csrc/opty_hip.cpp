@@ -68,6 +68,8 @@ struct IndexDims {
     long long offset; // first global constraint node of this shard
     long long count;  // constraint nodes of this shard
     int n, q, M, C, tail, method;
+    int P;                 // stored entries per node block
+    const int *pattern;    // (j, k) per stored entry, or null: e -> (e/C, e%C)
 };
 
 __device__ __forceinline__ void index_of(const IndexDims &d, long long i,
@@ -96,7 +98,7 @@ __device__ __forceinline__ void index_of(const IndexDims &d, long long i,
 __global__ void __launch_bounds__(256)
 opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
                     int nodes_per_block) {
-    const int P = d.M*d.C;
+    const int P = d.P;
     const long long i0 = (long long)blockIdx.x*nodes_per_block;
     for (int s = 0; s < nodes_per_block; ++s) {
         const long long i = i0 + s;           // local constraint node
@@ -104,8 +106,14 @@ opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
         long long *r = rows + i*P;
         long long *c = cols + i*P;
         for (int e = threadIdx.x; e < P; e += blockDim.x) {
-            const int j = e/d.C;
-            const int k = e - j*d.C;
+            int j, k;
+            if (d.pattern) {
+                j = d.pattern[2*e];
+                k = d.pattern[2*e + 1];
+            } else {
+                j = e/d.C;
+                k = e - j*d.C;
+            }
             long long row, col;
             index_of(d, i + d.offset, j, k, row, col);
             r[e] = row;
@@ -126,6 +134,7 @@ struct opty_hip_problem {
     bool uni_dirty = true;   // node-invariant table needs (re)computing
     long long *d_inst_idx = nullptr, *d_inst_rows = nullptr,
               *d_inst_cols = nullptr;
+    int *d_pattern = nullptr;   // (j, k) per stored block entry when pruned
     double *d_free = nullptr, *d_con = nullptr, *d_jac = nullptr;  // staging
     long long *d_rows = nullptr, *d_cols = nullptr;                // staging
     double h = 0.0;
@@ -133,7 +142,7 @@ struct opty_hip_problem {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int64_t ncon_nodes() const { return d.N - 1; }
-    int64_t P() const { return (int64_t)d.M*d.C; }
+    int64_t P() const { return (int64_t)d.P; }
     int64_t num_free() const { return (int64_t)(d.n + d.q)*d.N + d.r + d.s; }
     int64_t num_con() const { return (int64_t)d.M*ncon_nodes() + d.num_inst; }
     int64_t nnz() const { return P()*ncon_nodes() + d.nnz_inst; }
@@ -412,6 +421,9 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
                     opty_hip_problem **out) {
     if (!desc || !code_object_path || !out) return fail("null argument");
     if (desc->N < 2) return fail("need at least 2 collocation nodes");
+    if (desc->P < 0 || desc->P > desc->M*desc->C)
+        return fail("P = %d stored entries per block, block is %d x %d",
+                    desc->P, desc->M, desc->C);
     if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
         desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1 ||
         desc->con_wgs_per_block < 1)
@@ -470,7 +482,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
     if (!p) return 0;
     (void)hipSetDevice(p->d.device);
     (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
+    void *bufs[] = {p->d_pattern, p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
                     p->d_cols};
     for (void *b : bufs)
@@ -565,6 +577,20 @@ int opty_hip_set_instance_indices(opty_hip_problem *p,
     return 0;
 }
 
+int opty_hip_set_block_pattern(opty_hip_problem *p, const int32_t *jk) {
+    if (!p || !jk) return fail("null argument");
+    if (int rc = use_device(p)) return rc;
+    for (int e = 0; e < p->d.P; ++e)
+        if (jk[2*e] < 0 || jk[2*e] >= p->d.M || jk[2*e + 1] < 0 ||
+            jk[2*e + 1] >= p->d.C)
+            return fail("block pattern entry %d = (%d, %d) outside %d x %d",
+                        e, jk[2*e], jk[2*e + 1], p->d.M, p->d.C);
+    if (int rc = ensure(&p->d_pattern, (size_t)2*p->d.P)) return rc;
+    HIP_TRY(hipMemcpy(p->d_pattern, jk, 2*p->d.P*sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
 int64_t opty_hip_num_free(const opty_hip_problem *p) {
     return p ? p->num_free() : -1;
 }
@@ -621,6 +647,11 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     d.C = p->d.C;
     d.tail = p->d.r + p->d.s;
     d.method = p->d.method;
+    d.P = p->d.P;
+    d.pattern = p->d_pattern;
+    if (p->d.P != p->d.M*p->d.C && !p->d_pattern)
+        return fail("the block pattern was never set "
+                    "(opty_hip_set_block_pattern)");
     const int P = (int)p->P();
     // enough entries per block to keep 256 lanes busy
     int npb = P >= 1024 ? 1 : (1024 + P - 1)/P;

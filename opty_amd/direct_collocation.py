@@ -46,7 +46,11 @@ class ConstraintCollocator(object):
       ``'cython'`` / ``'numpy'`` do not exist here;
     * ``parallel`` is accepted and ignored (a GPU launch is always parallel);
     * ``tmp_dir`` is the code-object cache directory;
-    * extra keyword ``device`` (HIP ordinal) and ``emit_options``.
+    * extra keywords ``device`` (HIP ordinal), ``emit_options`` and
+      ``prune_zeros``: opt-in, drops the structurally zero entries of the
+      per-node block from ``jacobian(free)`` / ``jacobian_indices()`` (the
+      reference keeps them, ``opty/direct_collocation.py:2589-2593``; 61 % of
+      the 10-link pendulum's block) -- SURVEY.md 8(f) rank 3.
 
     Notation: N nodes, M equations, n states, m input trajectories, q unknown
     input trajectories, r unknown parameters, s variable duration, o instance
@@ -59,7 +63,8 @@ class ConstraintCollocator(object):
                  instance_constraints=None, time_symbol=None, tmp_dir=None,
                  integration_method='backward euler', parallel=False,
                  show_compile_output=False, backend='hip', device=0,
-                 emit_options=None):
+                 emit_options=None, prune_zeros=False):
+        self._prune_zeros = bool(prune_zeros)
         self._eom = sm.ImmutableDenseMatrix(equations_of_motion)
         if self._eom.shape[1] != 1:
             raise ValueError('equations_of_motion must be a column matrix.')
@@ -501,7 +506,7 @@ class ConstraintCollocator(object):
             self.parameters, self.num_known_parameters,
             self.time_interval_symbol, self._variable_duration,
             self._wrt(), self.integration_method, instance,
-            implicit=self._implicit_chain())
+            implicit=self._implicit_chain(), prune_zeros=self._prune_zeros)
         return self._program
 
     def generate_source(self):
@@ -516,7 +521,7 @@ class ConstraintCollocator(object):
             q=self.num_unknown_input_trajectories,
             p_known=self.num_known_parameters,
             r=self.num_unknown_parameters, s=int(self._variable_duration),
-            C=prog.C,
+            C=prog.C, P=prog.P,
             method=0 if self.integration_method == 'backward euler' else 1,
             num_inst=self.num_instance_constraints,
             nnz_inst=len(self._inst_rows),
@@ -554,6 +559,8 @@ class ConstraintCollocator(object):
             callable(v) for v in self.known_trajectory_map.values())
         if self.num_known_input_trajectories and not self._callable_known:
             hip.set_known_trajectories(self._known_trajectory_array(None))
+        if self._program.pruned:
+            hip.set_block_pattern(self._program.pattern)
         if self.num_instance_constraints:
             idx = self.instance_constraints_free_index_map
             hip.set_instance_indices([idx[f] for f in self._inst_atoms],

@@ -110,7 +110,7 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
 class _Desc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int64)] + [
         (name, ctypes.c_int32) for name in (
-            'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'method',
+            'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'P', 'method',
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device')]
@@ -138,6 +138,7 @@ _SIGNATURES = {
     'opty_hip_set_known_trajectories': (ctypes.c_int,
                                         [_P, _P, ctypes.c_int32]),
     'opty_hip_set_instance_indices': (ctypes.c_int, [_P, _P, _P, _P]),
+    'opty_hip_set_block_pattern': (ctypes.c_int, [_P, _P]),
     'opty_hip_num_free': (ctypes.c_int64, [_P]),
     'opty_hip_num_constraints': (ctypes.c_int64, [_P]),
     'opty_hip_nnz': (ctypes.c_int64, [_P]),
@@ -288,6 +289,11 @@ class HipProblem(object):
         assert v.size == self.desc['m_known']*self.desc['N']
         _check(self._lib.opty_hip_set_known_trajectories(
             self._h, _ptr(v), HOST))
+
+    def set_block_pattern(self, pattern):
+        jk = np.ascontiguousarray(pattern, dtype=np.int32).reshape(-1, 2)
+        assert len(jk) == self.desc['P']
+        _check(self._lib.opty_hip_set_block_pattern(self._h, _ptr(jk)))
 
     def set_instance_indices(self, atom_index, rows, cols):
         a = np.ascontiguousarray(atom_index, dtype=np.int64)

@@ -206,7 +206,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     import torch
     if not torch.cuda.is_available():
         assert lib.opty_hip_device_count() == 0
-        desc = hb._Desc(N=10, n=1, M=1, C=2, jac_wgs_per_block=1,
+        desc = hb._Desc(N=10, n=1, M=1, C=2, P=2, jac_wgs_per_block=1,
                         fused_wgs_per_block=1, con_wgs_per_block=1,
                         jac_waves_per_wg=1)
         handle = ctypes.c_void_p()
@@ -327,3 +327,28 @@ def test_objective_rejections():
                                 'backward euler', t)
     with pytest.raises(NotImplementedError):
         build_objective_program(x**2, [x], [], [], 'backward euler', t)
+
+
+@pytest.mark.parametrize('name', ['config3_10link_small',
+                                  'pend3_link_midpoint_small',
+                                  'chaplygin_mid_small'])
+def test_pruned_block_pattern(name):
+    """``prune_zeros=True`` keeps exactly the entries whose partial is not
+    identically zero, and the kept values are the reference's values."""
+    meta, z = gu.load(name)
+    dense = ConstraintCollocator(**problems.build(name))
+    pruned = ConstraintCollocator(prune_zeros=True, **problems.build(name))
+    pd, pp = dense._build_program(), pruned._build_program()
+    assert pd.P == meta['M']*meta['C'] and pp.P < pd.P
+    kept = [(j, k) for (j, k), node in zip(pd.pattern, pd.jac_out)
+            if node != pd.dag.zero]
+    assert pp.pattern == kept
+    _, jac = dag_interp.evaluate_collocator(pruned, z['free'])
+    N, P = meta['N'], meta['M']*meta['C']
+    full = z['jac'][:P*(N - 1)].reshape(N - 1, P)
+    sel = [j*meta['C'] + k for j, k in kept]
+    gu.assert_close(jac[:pp.P*(N - 1)].reshape(N - 1, pp.P), full[:, sel],
+                    1e-10, what='pruned values')
+    # everything that was dropped is exactly zero in the reference's output
+    dropped = sorted(set(range(P)) - set(sel))
+    assert not full[:, dropped].any()

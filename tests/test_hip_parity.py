@@ -301,3 +301,28 @@ def test_problem_facade_matches_reference():
         prob.extract_values(free, sm.Symbol('nope'))
     with pytest.raises(ImportError, match='cyipopt'):
         prob.solve(free)
+
+
+@pytest.mark.parametrize('name', ['config3_10link_small',
+                                  'pend3_link_midpoint_small',
+                                  'chaplygin_mid_small',
+                                  'vardur_pendulum_small'])
+def test_pruned_sparsity_reassembles_to_reference(name):
+    """Opt-in ``prune_zeros=True``: fewer triplets, same matrix.  The dense
+    re-assembly (last write wins, the reference's ``_coo_matrix``) of the
+    pruned triplets equals that of the reference's full triplets."""
+    from opty_amd.utils import coo_to_dense
+    import opty_amd
+    meta, z = gu.load(name)
+    col = opty_amd.ConstraintCollocator(prune_zeros=True,
+                                        **problems.build(name))
+    jac = col.generate_jacobian_function()(z['free'])
+    rows, cols = col.jacobian_indices()
+    assert len(jac) == len(rows) == len(cols) < len(z['jac'])
+    ref = coo_to_dense(z['jac'], z['rows'], z['cols'])
+    got = np.zeros_like(ref)
+    got[rows, cols] = jac
+    gu.assert_close(got, ref, RTOL, what='dense Jacobian')
+    # the constraints are untouched by the option
+    gu.assert_close(col.generate_constraint_function()(z['free']), z['con'],
+                    RTOL, what='con')

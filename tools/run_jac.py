@@ -11,11 +11,12 @@ from opty_amd.codegen.emit_hip import EmitOptions
 spec = sys.argv[1] if len(sys.argv) > 1 else 'default'
 what = {'jac': hb.EVAL_JAC, 'con': hb.EVAL_CON, 'fused': hb.EVAL_FUSED}[sys.argv[2] if len(sys.argv) > 2 else 'jac']
 opts = EmitOptions() if spec == 'default' else parse(spec)
-col = opty_amd.ConstraintCollocator(emit_options=opts, **problems.build('config3_10link'))
+workload = os.environ.get('OPTY_WORKLOAD', 'config3_10link')
+col = opty_amd.ConstraintCollocator(emit_options=opts, **problems.build(workload))
 hip = col.hip
 dev = torch.device('cuda:0')
 hip.set_stream(torch.cuda.current_stream().cuda_stream)
-free = torch.from_numpy(problems.make_free(col.num_free)).to(dev)
+free = torch.from_numpy(problems.make_free(col.num_free, variable_duration=col._variable_duration)).to(dev)
 con = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
 jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
 print(hip.time_eval(what, free, con, jac, 10))
