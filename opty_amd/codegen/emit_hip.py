@@ -123,18 +123,27 @@ class _Body(object):
         self.leaf = leaf
 
     def new_scope(self):
-        """Starts a new scope (chunk).  All leaf fetches of the scope that
-        just ended are hoisted to its top so that the scalar loads / LDS reads
-        are issued back to back (and merge into wide s_load instructions)
-        instead of one load + wait in front of every first use."""
+        """Starts a new scope (chunk): leaves are re-fetched in it."""
         self.end_scope()
         self.scope = {}
         self.scope_id += 1
 
     def end_scope(self):
+        """Ends a fetch batch.  The scalar (node-invariant) loads issued
+        since the last call are hoisted to the point where the batch began,
+        so that they are issued back to back and merge into wide ``s_load``
+        instructions instead of one load + wait in front of every first use.
+        Batches are kept small (one output entry): hoisting a whole chunk's
+        loads needs hundreds of SGPRs for a 24-link system and spills.
+        (Tried and rejected: an LDS table of these values -- the compiler
+        prefetches the LDS reads far ahead and the VGPR count explodes;
+        scheduling / memory barriers between entries -- no effect on the
+        allocation.)"""
         self.lines[self.scope_start:self.scope_start] = self.fetches
         self.fetches = []
         self.scope_start = len(self.lines)
+
+    begin_entry = end_scope
 
     def ref(self, i):
         d = self.dag
@@ -154,7 +163,13 @@ class _Body(object):
         if src is None:
             return False
         name = 'f%d_%d' % (i, self.scope_id)
-        self.fetches.append('const double %s = %s;' % (name, src))
+        line = 'const double %s = %s;' % (name, src)
+        # only scalar loads are hoisted; per-lane LDS reads stay at their
+        # first use (hoisted, every input of the batch is live at once)
+        if self.dag.uni[i]:
+            self.fetches.append(line)
+        else:
+            self.lines.append(line)
         self.scope[i] = name
         return True
 
@@ -441,6 +456,7 @@ class _ModuleWriter(object):
             for c0, c1 in self._chunks(e0, e1 + 15):
                 body.new_scope()
                 for v in range(c0, c1):
+                    body.begin_entry()
                     body.lines.append('ring[%d + lane] = %s;'
                                       % ((v % R)*TS, value(v % p.P)))
                 body.lines.append('opty_wave_sync();')
@@ -465,6 +481,7 @@ class _ModuleWriter(object):
         for c0, c1 in self._chunks(e0, e1):
             body.new_scope()
             for e in range(c0, c1):
+                body.begin_entry()
                 body.lines.append('ring[%d + lane] = %s;'
                                   % ((e - c0)*TS, value(e)))
             body.lines.append('opty_wave_sync();')

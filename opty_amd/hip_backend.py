@@ -179,9 +179,15 @@ def load_library():
         except ImportError:
             pass
         if not os.path.exists(LIB_PATH):
-            raise HipBackendError(
-                '%s is missing: run `python -c "import __graft_entry__ as g; '
-                'g.build()"` (there is no CPU fallback)' % LIB_PATH)
+            # not built yet (fresh checkout): build it from source with hipcc;
+            # there is no CPU fallback, so a missing compiler is an error
+            try:
+                build_runtime_library()
+            except HipBackendError as err:
+                raise HipBackendError(
+                    '%s is missing and could not be built (%s): run `python '
+                    '-c "import __graft_entry__ as g; g.build()"`'
+                    % (LIB_PATH, err))
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
