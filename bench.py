@@ -223,7 +223,7 @@ def main():
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(kw)
         print(json.dumps(out))
     if world > 1:
