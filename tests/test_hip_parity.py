@@ -326,3 +326,18 @@ def test_pruned_sparsity_reassembles_to_reference(name):
     # the constraints are untouched by the option
     gu.assert_close(col.generate_constraint_function()(z['free']), z['con'],
                     RTOL, what='con')
+
+
+def test_end_to_end_parameter_identification():
+    """The reference's CI smoke test (``examples/vyasarayani2011.py``) in
+    miniature: the Problem callbacks drive an NLP solver (SciPy's
+    trust-constr here; IPOPT is absent) to the true pendulum parameter."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'vyasarayani_scipy', os.path.join(os.path.dirname(__file__), '..',
+                                          'examples', 'vyasarayani_scipy.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    p_hat, res = mod.main(verbose=False)
+    assert abs(p_hat - 10.0) < 0.2, p_hat
