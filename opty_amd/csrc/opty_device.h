@@ -3,25 +3,30 @@
 //
 // Work decomposition (the replacement for the reference's
 // `for i in prange(n)` node loop, opty/utils.py:524-526):
-//   * one 64-lane wavefront == one workgroup == 64 consecutive constraint
-//     nodes, lane l owns node  node0 + l;
+//   * one 64-lane wavefront == 64 consecutive constraint nodes, lane l owns
+//     node  node0 + l; a workgroup is one wave, or W waves that evaluate
+//     different entry ranges of the same 64 nodes and share the input slab;
 //   * the trajectory rows those nodes need (65 time nodes per row: the one-node
 //     halo of opty/direct_collocation.py:2411-2413) are pulled from HBM with
-//     one coalesced 512-byte load per row into an LDS slab, and every lane then
-//     picks its "current" and "adjacent" value from LDS;
+//     one coalesced 512-byte load per row into an LDS slab (the generated
+//     prologue issues every load before the first LDS write), and every lane
+//     then picks its "current" and "adjacent" value from LDS;
 //   * the per-node expressions (generated straight-line float64 code) are
 //     evaluated in registers;
 //   * constraints are stored equation-major straight from registers (lane ==
 //     node == consecutive addresses, opty/direct_collocation.py:2446);
 //   * the Jacobian block of a node is node-major in memory
 //     (jac[i*P + j*C + k], opty/direct_collocation.py:2885-2887), i.e. lanes
-//     are 8*P bytes apart.  The wave therefore stages KC consecutive entries of
-//     all its 64 nodes in an LDS tile (entry-major, conflict-free 8-byte
-//     writes), and flushes the tile with 16-byte-per-lane stores in which 2*KC
-//     / 16 ... lanes cover one node's KC*8 contiguous bytes.
+//     are 8*P bytes apart.  A wave therefore stages entries of all its 64
+//     nodes in an LDS ring tile (entry-major, conflict-free 8-byte writes) and
+//     flushes whole 128-byte lines of the flat output with branch-free
+//     16-byte buffer stores (opty_flush_lines below); tiny blocks (P < 64)
+//     use the simple per-chunk flushes opty_flush16 / opty_flush8.
 //
-// A single-wave workgroup needs no s_barrier: LDS operations of one wave
-// execute in order, so a compiler-level fence is all the tile hand-off needs.
+// The waves of a workgroup exchange data only through their own ring tile:
+// LDS operations of one wave execute in order, so a compiler-level fence
+// (opty_wave_sync) is all the tile hand-off needs; the shared slab is
+// published with one __syncthreads() when W > 1.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,21 +57,6 @@ __device__ __forceinline__ void opty_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// Loads time nodes [t0, t0+64] of one trajectory row into slab row `r`.
-// `tmax` is the last valid time node (N-1); loads are clamped, the clamped
-// lanes belong to nodes that are never stored.
-__device__ __forceinline__ void opty_slab_load(double *slab, int r,
-                                               const double *row,
-                                               long long t0, long long tmax,
-                                               int lane) {
-    long long t = t0 + lane;
-    slab[r*OPTY_TS + lane] = row[t < tmax ? t : tmax];
-    if (lane == 0) {
-        long long te = t0 + OPTY_WAVE;
-        slab[r*OPTY_TS + OPTY_WAVE] = row[te < tmax ? te : tmax];
-    }
 }
 
 // Flushes an entry-major LDS tile (KC entries x 64 nodes, row stride OPTY_TS)

@@ -103,6 +103,42 @@ contig_store(double *out, long long row_doubles, long long nnodes, int lds_pad) 
     }
 }
 
+// pattern 3: ONE chunk per short-lived workgroup: block b writes the SEG-byte
+// pieces (line-aligned) of chunk (b % nchunk) of node block (b / nchunk).
+template <int SEG>
+__global__ void __launch_bounds__(64)
+chunk_store(double *out, long long row_doubles, long long nnodes, int nchunk) {
+    const int lane = threadIdx.x;
+    const long long blk = blockIdx.x/nchunk;
+    const int c = blockIdx.x % nchunk;
+    const long long node0 = blk*64;
+    if (node0 >= nnodes) return;
+    constexpr int LPN = SEG/16, NPS = 64/LPN;
+    const int sub = lane % LPN, nsel = lane/LPN;
+    const long long row_bytes = row_doubles*8;
+    char *base = (char *)out + node0*row_bytes;
+    const long long region = 64*row_bytes;
+#pragma unroll
+    for (int p = 0; p < 64/NPS; ++p) {
+        const int nd = p*NPS + nsel;
+        long long start = nd*row_bytes + (long long)c*SEG;
+        long long addr = (long long)base + start;
+        long long al = (addr + 127)/128*128 - (long long)base;
+        long long off = al + sub*16;
+        if (node0 + nd < nnodes && off + 16 <= region) {
+            double2 v = make_double2((double)lane, (double)c);
+            *reinterpret_cast<double2 *>(base + off) = v;
+        }
+    }
+}
+
+// plain streaming fill with 64-thread blocks, one 1 KB store per block
+__global__ void __launch_bounds__(64)
+stream_fill64(double2 *out, long long n2) {
+    long long i = (long long)blockIdx.x*64 + threadIdx.x;
+    if (i < n2) out[i] = make_double2(1.0, 2.0);
+}
+
 // plain grid-stride fill, 256-thread blocks (the classic streaming write)
 __global__ void __launch_bounds__(256)
 stream_fill(double2 *out, long long n2) {
@@ -173,7 +209,24 @@ int main() {
             }
         }
     }
+    {
+        const long long row = 990;
+        const double gb = nnodes*row*8/1e9;
+        const int nblk = (int)((nnodes + 63)/64);
+        for (int seg : {256, 512, 1024}) {
+            const int nchunk = (int)(row*8/seg);
+            float ms;
+            if (seg == 256) ms = time_ms([&] { hipLaunchKernelGGL((chunk_store<256>), dim3(nblk*nchunk), dim3(64), 0, 0, out, row, nnodes, nchunk); });
+            else if (seg == 512) ms = time_ms([&] { hipLaunchKernelGGL((chunk_store<512>), dim3(nblk*nchunk), dim3(64), 0, 0, out, row, nnodes, nchunk); });
+            else ms = time_ms([&] { hipLaunchKernelGGL((chunk_store<1024>), dim3(nblk*nchunk), dim3(64), 0, 0, out, row, nnodes, nchunk); });
+            printf("chunk-per-block seg%d  %.4f ms %7.0f GB/s (%d blocks)\n", seg, ms, gb/ms*1e3*(nchunk*seg)/(row*8.0), nblk*nchunk);
+        }
+    }
     const long long n2 = nnodes*990/2;
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL(stream_fill64, dim3((unsigned)((n2 + 63)/64)), dim3(64), 0, 0, (double2 *)out, n2); });
+        printf("stream_fill64 (1 KB per 64-thread block) %.4f ms %7.0f GB/s\n", ms, n2*16/1e9/ms*1e3);
+    }
     for (int g : {2048, 8192, 65536}) {
         float ms = time_ms([&] { hipLaunchKernelGGL(stream_fill, dim3(g),
                                                     dim3(256), 0, 0,
