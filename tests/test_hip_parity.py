@@ -341,3 +341,33 @@ def test_end_to_end_parameter_identification():
     spec.loader.exec_module(mod)
     p_hat, res = mod.main(verbose=False)
     assert abs(p_hat - 10.0) < 0.2, p_hat
+
+
+def test_unaligned_output_pointers():
+    """The line-aligned flush keys on the ACTUAL address: an output buffer that
+    starts 8, 24 or 120 bytes off a 128-byte line (odd / even phases, pieces
+    straddling node rows) gives the same values as an aligned one."""
+    import torch
+    from opty_amd import hip_backend as hb
+    col = _collocator('config3_10link', num_nodes=1000)
+    hip = col.hip
+    dev = torch.device('cuda:0')
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    free = torch.from_numpy(problems.make_free(col.num_free, seed=8)).to(dev)
+    ref = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+    hip.eval_jac(free, ref, hb.DEVICE)
+    for shift in (1, 3, 15, 16):
+        buf = torch.full((hip.nnz + 64,), float('nan'), dtype=torch.float64,
+                         device=dev)
+        out = buf[shift:shift + hip.nnz]
+        hip.eval_jac(free, out, hb.DEVICE)
+        torch.cuda.synchronize()
+        # entries at the seam of two waves' ranges are evaluated by both
+        # (line ownership decides whose value lands): same expression,
+        # independently scheduled code -> last-ulp differences only
+        gu.assert_close(out.cpu().numpy(), ref.cpu().numpy(), 1e-13,
+                        what='shift %d' % shift)
+        # nothing outside the output range was touched
+        assert torch.isnan(buf[:shift]).all()
+        assert torch.isnan(buf[shift + hip.nnz:]).all()
+    hip.set_stream(None)
