@@ -132,6 +132,27 @@ chunk_store(double *out, long long row_doubles, long long nnodes, int nchunk) {
     }
 }
 
+// 256-thread workgroups, each streaming its own contiguous region (4 KB per
+// workgroup-instruction)
+__global__ void __launch_bounds__(256)
+contig256(double2 *out, long long n2, long long per_block) {
+    const long long b0 = (long long)blockIdx.x*per_block;
+    long long e = b0 + per_block < n2 ? b0 + per_block : n2;
+    for (long long i = b0 + threadIdx.x; i < e; i += 256)
+        out[i] = make_double2(1.0, 2.0);
+}
+
+// short-lived 256-thread blocks, but block b writes the (b / S)-th 4 KB piece
+// of stream (b % S): S interleaved long streams instead of one global sweep
+__global__ void __launch_bounds__(256)
+strided_fill(double2 *out, long long n2, int S) {
+    const long long pieces = (n2 + 255)/256;          // 4 KB pieces
+    const long long per_stream = (pieces + S - 1)/S;
+    const long long piece = (blockIdx.x % S)*per_stream + blockIdx.x/S;
+    const long long i = piece*256 + threadIdx.x;
+    if (blockIdx.x/S < per_stream && i < n2) out[i] = make_double2(1.0, 2.0);
+}
+
 // plain streaming fill with 64-thread blocks, one 1 KB store per block
 __global__ void __launch_bounds__(64)
 stream_fill64(double2 *out, long long n2) {
@@ -223,6 +244,17 @@ int main() {
         }
     }
     const long long n2 = nnodes*990/2;
+    for (int nb : {512, 2048, 8192}) {
+        const long long per_block = (n2 + nb - 1)/nb;
+        float ms = time_ms([&] { hipLaunchKernelGGL(contig256, dim3(nb), dim3(256), 0, 0, (double2 *)out, n2, per_block); });
+        printf("contig256 blocks=%d (%.0f KB each) %.4f ms %7.0f GB/s\n", nb, per_block*16/1024.0, ms, n2*16/1e9/ms*1e3);
+    }
+    for (int S : {1, 64, 1024, 2048}) {
+        const long long pieces = (n2 + 255)/256;
+        const long long per_stream = (pieces + S - 1)/S;
+        float ms = time_ms([&] { hipLaunchKernelGGL(strided_fill, dim3((unsigned)(per_stream*S)), dim3(256), 0, 0, (double2 *)out, n2, S); });
+        printf("strided_fill streams=%d %.4f ms %7.0f GB/s\n", S, ms, n2*16/1e9/ms*1e3);
+    }
     {
         float ms = time_ms([&] { hipLaunchKernelGGL(stream_fill64, dim3((unsigned)((n2 + 63)/64)), dim3(64), 0, 0, (double2 *)out, n2); });
         printf("stream_fill64 (1 KB per 64-thread block) %.4f ms %7.0f GB/s\n", ms, n2*16/1e9/ms*1e3);
