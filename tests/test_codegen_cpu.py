@@ -352,3 +352,24 @@ def test_pruned_block_pattern(name):
     # everything that was dropped is exactly zero in the reference's output
     dropped = sorted(set(range(P)) - set(sel))
     assert not full[:, dropped].any()
+
+
+@pytest.mark.parametrize('name', ['instance_constraints',
+                                  'variable_duration', 'msd_backward_euler',
+                                  'msd_midpoint'])
+def test_reference_unit_test_fixtures_on_dag(name):
+    """The reference's own N = 4 fixtures on the product's host logic + DAG
+    (instance-constraint free-index map and literal tail indices included)."""
+    import reference_cases
+    case = reference_cases.ALL[name]()
+    col = ConstraintCollocator(**case['kw'])
+    con, jac = dag_interp.evaluate_collocator(col, case['free'])
+    np.testing.assert_allclose(con, case['con'], rtol=1e-12)
+    if 'free_index' in case:
+        got = {str(k): v for k, v in
+               col.instance_constraints_free_index_map.items()}
+        assert got == case['free_index']
+    if case['rows'] is not None:
+        r, c = col._instance_constraints_jacobian_indices()
+        np.testing.assert_array_equal(r, case['rows'][-len(r):])
+        np.testing.assert_array_equal(c, case['cols'][-len(c):])

@@ -371,3 +371,28 @@ def test_unaligned_output_pointers():
         assert torch.isnan(buf[:shift]).all()
         assert torch.isnan(buf[shift + hip.nnz:]).all()
     hip.set_stream(None)
+
+
+@pytest.mark.parametrize('name', ['instance_constraints',
+                                  'variable_duration', 'msd_backward_euler',
+                                  'msd_midpoint'])
+def test_reference_unit_test_fixtures(name):
+    """The reference's own N = 4 unit-test fixtures through the HIP path:
+    literal ``jacobian_indices()`` arrays
+    (``opty/tests/test_direct_collocation.py:1594-1600``, ``:1916-1930``),
+    hand-derived constraint values and the dense Jacobian assembled with the
+    reference's ``_coo_matrix`` semantics (``:2010-2039``)."""
+    import reference_cases
+    import opty_amd
+    from opty_amd.utils import coo_to_dense
+    case = reference_cases.ALL[name]()
+    col = opty_amd.ConstraintCollocator(**case['kw'])
+    con = col.generate_constraint_function()(case['free'])
+    jac = col.generate_jacobian_function()(case['free'])
+    rows, cols = col.jacobian_indices()
+    np.testing.assert_allclose(con, case['con'], rtol=1e-12)
+    if case['rows'] is not None:
+        np.testing.assert_array_equal(rows, case['rows'])
+        np.testing.assert_array_equal(cols, case['cols'])
+    np.testing.assert_allclose(coo_to_dense(jac, rows, cols), case['dense'],
+                               rtol=1e-12, atol=1e-12)

@@ -137,3 +137,23 @@ def test_error_behaviour():
                                    np.zeros(3)}
     with pytest.raises(ValueError):
         OracleCollocator(**bad)
+
+
+@pytest.mark.parametrize('name', ['instance_constraints',
+                                  'variable_duration', 'msd_backward_euler',
+                                  'msd_midpoint'])
+def test_reference_unit_test_fixtures(name):
+    """The reference's own N = 4 fixtures (literal index arrays, hand-derived
+    values) against the oracle."""
+    import reference_cases
+    case = reference_cases.ALL[name]()
+    orc = OracleCollocator(name='ref_' + name, **case['kw'])
+    con = orc.generate_constraint_function()(case['free'])
+    jac = orc.generate_jacobian_function()(case['free'])
+    rows, cols = orc.jacobian_indices()
+    np.testing.assert_allclose(con, case['con'], rtol=1e-12)
+    if case['rows'] is not None:
+        np.testing.assert_array_equal(rows, case['rows'])
+        np.testing.assert_array_equal(cols, case['cols'])
+    np.testing.assert_allclose(dense_from_coo(jac, rows, cols),
+                               case['dense'], rtol=1e-12, atol=1e-12)
