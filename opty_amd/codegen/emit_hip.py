@@ -59,7 +59,13 @@ class EmitOptions(object):
     """
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
-                 flush_unroll=4, waves=1, store_aux=18, con_rows_per_wave=0):
+                 flush_unroll=4, waves=1, store_aux=18, con_rows_per_wave=0,
+                 interleave=0):
+        # 1: every wave gets a cheap strip and an expensive strip of the
+        # block (see _ModuleWriter.group_ranges); measured slower than one
+        # contiguous strip per wave on MI355X (more address streams), kept
+        # for experiments
+        self.interleave = int(interleave)
         self.con_rows_per_wave = int(con_rows_per_wave)
         # cache-policy bits of the flush stores: nt | sc1 -- the Jacobian is
         # written once and never re-read by the kernel; streaming it past the
@@ -85,10 +91,10 @@ class EmitOptions(object):
 
     def key(self):
         return ('chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d '
-                'waves=%d store_aux=%d con_rows_per_wave=%d' % (
+                'waves=%d store_aux=%d con_rows_per_wave=%d interleave=%d' % (
                     self.chunk, self.groups, self.max_live, self.ablate,
                     self.flush_unroll, self.waves, self.store_aux,
-                    self.con_rows_per_wave))
+                    self.con_rows_per_wave, self.interleave))
 
 
 def _lit(v):
@@ -361,18 +367,47 @@ class _ModuleWriter(object):
         lines; the last range wraps into entries 0..14 (of the next node)."""
         return e1 + 15 if self.line_mode() else e1
 
+    def _strip_cost(self, e0, e1):
+        """Evaluation work of a strip: DAG nodes that have to be computed per
+        node (node-invariant values and constants are free)."""
+        d, p = self.dag, self.p
+        roots = [p.jac_out[v % p.P] for v in range(e0, self._virtual_end(e1))]
+        return sum(1 for i in d.reachable(roots)
+                   if d.op[i] not in (ir.CONST, ir.INPUT) and not d.uni[i])
+
     def group_ranges(self):
-        """Splits the P entries of the block into G contiguous ranges whose
-        boundaries are multiples of the chunk width (hence even).  With
-        ``groups=None`` the number of groups is the smallest for which every
-        group's estimated live temporaries stay below ``max_live``."""
+        """Assigns the P entries of the block to G waves.  The block is cut
+        into strips (contiguous entry ranges whose boundaries are multiples of
+        a 16-double line, or of the chunk width for tiny blocks); a wave gets
+        one strip, or -- ``interleave`` -- two: the cheapest remaining and the
+        most expensive remaining one, so that every wave carries the same mix
+        of store-only entries (structural zeros, constants) and evaluation
+        work instead of half the waves only storing and half only computing.
+        With ``groups=None`` G is the smallest number for which every wave's
+        estimated live temporaries stay below ``max_live``.  Returns a list of
+        groups, each a list of ``(e0, e1)`` strips in evaluation order."""
         P, K = self.p.P, self.o.chunk
         unit = 16 if self.line_mode() else K
         nunits = max(1, P//unit if self.line_mode() else (P + K - 1)//K)
+        two = bool(self.o.interleave) and self.line_mode()
+
+        def cut(S):
+            b = [((g*nunits)//S)*unit for g in range(S)] + [P]
+            return [(b[g], b[g + 1]) for g in range(S)]
 
         def split(G):
-            b = [((g*nunits)//G)*unit for g in range(G)] + [P]
-            return [(b[g], b[g + 1]) for g in range(G)]
+            if not two or 2*G > nunits//2:
+                return [[rg] for rg in cut(G)]
+            strips = cut(2*G)
+            order = sorted(range(2*G),
+                           key=lambda k: (self._strip_cost(*strips[k]), k))
+            groups = []
+            for g in range(G):
+                cheap, dear = strips[order[g]], strips[order[2*G - 1 - g]]
+                # alternate the order so that at any time some waves store
+                # while others evaluate
+                groups.append([cheap, dear] if g % 2 == 0 else [dear, cheap])
+            return groups
 
         if self.o.groups is not None:
             return split(max(1, min(int(self.o.groups), nunits)))
@@ -381,15 +416,17 @@ class _ModuleWriter(object):
         # even an all-constant block yields enough waves to fill the chip
         G = max(1, min(nunits, (P + 255)//256))
         while True:
-            ranges = split(G)
+            groups = split(G)
             worst = max(
                 _max_live(self.dag,
                           [[self.p.jac_out[v % P] for v in range(a, b)]
-                           for a, b in self._chunks(e0, self._virtual_end(e1))],
+                           for e0, e1 in grp
+                           for a, b in self._chunks(e0,
+                                                    self._virtual_end(e1))],
                           leaf)
-                for e0, e1 in ranges)
+                for grp in groups)
             if worst <= self.o.max_live or G >= min(nunits, 32):
-                return ranges
+                return groups
             G += 1
 
     # -- kernels ---------------------------------------------------------------
@@ -397,33 +434,36 @@ class _ModuleWriter(object):
         """Trajectory rows any wave of the kernel reads (the shared slab)."""
         p, d = self.p, self.dag
         roots = []
-        for (e0, e1), cons in zip(groups, con_of_group):
-            vend = self._virtual_end(e1) if e1 > e0 else e1
-            roots += [p.jac_out[v % p.P] for v in range(e0, vend)]
+        for grp, cons in zip(groups, con_of_group):
+            for e0, e1 in grp:
+                vend = self._virtual_end(e1) if e1 > e0 else e1
+                roots += [p.jac_out[v % p.P] for v in range(e0, vend)]
             roots += [p.con_out[j] for j in cons]
         needed = d.reachable(roots)
         return sorted({d.args[i][1] for i in needed if self._is_vec_input(i)})
 
-    def _ring_rows(self, e0, e1):
+    def _ring_rows(self, grp):
         K = self.o.chunk
-        if e1 <= e0:
+        width = max(e1 - e0 for e0, e1 in grp)
+        if width <= 0:
             return 0
         if self.line_mode():
             return K + 16
-        return min(K, e1 - e0)
+        return min(K, width)
 
-    def _group_body(self, e0, e1, con_rows, slab_of):
-        """Code for one wave evaluating Jacobian entries [e0, e1) and the
-        constraint rows ``con_rows`` of its 64 nodes.  Inputs come from the
-        workgroup's shared slab (``lds``), outputs are staged in the wave's
-        private ring tile (``ring``)."""
+    def _group_body(self, grp, con_rows, slab_of):
+        """Code for one wave evaluating the Jacobian entry strips ``grp``
+        (``[(e0, e1), ...]``, in this order) and the constraint rows
+        ``con_rows`` of its 64 nodes.  Inputs come from the workgroup's shared
+        slab (``lds``), outputs are staged in the wave's private ring tile
+        (``ring``)."""
         p, d = self.p, self.dag
         K = self.o.chunk
-        vend = self._virtual_end(e1) if e1 > e0 else e1
-        roots = [p.jac_out[v % p.P] for v in range(e0, vend)]
-        roots += [p.con_out[j] for j in con_rows]
+        roots = [p.con_out[j] for j in con_rows]
+        for e0, e1 in grp:
+            vend = self._virtual_end(e1) if e1 > e0 else e1
+            roots += [p.jac_out[v % p.P] for v in range(e0, vend)]
         needed = set(d.reachable(roots))
-        line_mode = self.line_mode() and e1 > e0
         R = K + 16
 
         def leaf(i):
@@ -449,34 +489,48 @@ class _ModuleWriter(object):
                 return '(double)(lane + %d)' % e
             return body.emit(p.jac_out[e])
 
-        if line_mode:
-            if e1 < p.P:
-                assert e1 + 15 <= p.P, 'last entry range must be >= 16 wide'
+        strips = [rg for rg in grp if rg[1] > rg[0]]
+        if strips and self.line_mode():
             body.lines.append('const int b0 = opty_line_phase(jrow);')
-            for c0, c1 in self._chunks(e0, e1 + 15):
-                body.new_scope()
-                for v in range(c0, c1):
-                    body.begin_entry()
-                    body.lines.append('ring[%d + lane] = %s;'
-                                      % ((v % R)*TS, value(v % p.P)))
-                body.lines.append('opty_wave_sync();')
-                nlp = 1
-                while 16*nlp < c1 - c0:
-                    nlp *= 2
-                body.lines.append(
-                    'opty_flush_lines<%d, %d, %d>(ring, jrow, %d, b0, %d, %d,'
-                    ' %d, %d, %d, %s, lane);' % (
-                        nlp, R, self.o.flush_unroll, p.P, c0 - 15,
-                        (c0 - 15) % R, e0, e1, c1, nv))
-                if e0 == 0 and c0 == 0:
-                    assert c1 >= 15
-                    if self.o.ablate != 'compute_only':
-                        body.lines.append('opty_head_piece<%d>(ring, jrow, '
-                                          '%d, b0, lane);' % (R, p.P))
-                body.lines.append('opty_wave_sync();')
-            body.end_scope()
-            return body.lines
+        for e0, e1 in strips:
+            body.lines.append('// strip %d %d' % (e0, e1))
+            if self.line_mode():
+                self._strip_lines(body, e0, e1, value, nv, R)
+            else:
+                self._strip_simple(body, e0, e1, value, nv)
+        body.end_scope()
+        return body.lines
 
+    def _strip_lines(self, body, e0, e1, value, nv, R):
+        """Ring tile + line-aligned flush of one strip (see opty_device.h)."""
+        p = self.p
+        if e1 < p.P:
+            assert e1 + 15 <= p.P, 'last entry range must be >= 16 wide'
+        for c0, c1 in self._chunks(e0, e1 + 15):
+            body.new_scope()
+            for v in range(c0, c1):
+                body.begin_entry()
+                body.lines.append('ring[%d + lane] = %s;'
+                                  % ((v % R)*TS, value(v % p.P)))
+            body.lines.append('opty_wave_sync();')
+            nlp = 1
+            while 16*nlp < c1 - c0:
+                nlp *= 2
+            body.lines.append(
+                'opty_flush_lines<%d, %d, %d>(ring, jrow, %d, b0, %d, %d,'
+                ' %d, %d, %d, %s, lane);' % (
+                    nlp, R, self.o.flush_unroll, p.P, c0 - 15,
+                    (c0 - 15) % R, e0, e1, c1, nv))
+            if e0 == 0 and c0 == 0:
+                assert c1 >= 15
+                if self.o.ablate != 'compute_only':
+                    body.lines.append('opty_head_piece<%d>(ring, jrow, '
+                                      '%d, b0, lane);' % (R, p.P))
+            body.lines.append('opty_wave_sync();')
+
+    def _strip_simple(self, body, e0, e1, value, nv):
+        """Per-chunk tile + flush for tiny blocks (P < 64)."""
+        p = self.p
         wide = (p.P % 2 == 0)
         for c0, c1 in self._chunks(e0, e1):
             body.new_scope()
@@ -491,8 +545,6 @@ class _ModuleWriter(object):
             body.lines.append('%s<%d>(ring, jrow + %d, %dLL, %s, lane);'
                               % (fl, w, c0, p.P, nv))
             body.lines.append('opty_wave_sync();')
-        body.end_scope()
-        return body.lines
 
     def _slab_fill(self, rows, slab_of, W):
         """Cooperative slab fill: the workgroup's W waves split the rows.  A
@@ -559,8 +611,8 @@ class _ModuleWriter(object):
 '''
 
     def kernel(self, name, groups, con_of_group, W=1):
-        """One kernel.  ``groups`` = list of entry ranges (e0, e1), one wave
-        each; ``con_of_group[g]`` = constraint rows stored by wave g.  A
+        """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
+        wave; ``con_of_group[g]`` = constraint rows stored by wave g.  A
         workgroup is ``W`` consecutive groups of one 64-node block: they share
         one input slab (filled cooperatively) and each owns a ring tile."""
         G = len(groups)
@@ -568,9 +620,9 @@ class _ModuleWriter(object):
         sets = (G + W - 1)//W
         rows = self._kernel_rows(groups, con_of_group)
         slab_of = {r: k for k, r in enumerate(rows)}
-        ring_rows = max([self._ring_rows(*g) for g in groups] + [0])
-        bodies = [self._group_body(e0, e1, con_of_group[g], slab_of)
-                  for g, (e0, e1) in enumerate(groups)]
+        ring_rows = max([self._ring_rows(g) for g in groups] + [0])
+        bodies = [self._group_body(grp, con_of_group[g], slab_of)
+                  for g, grp in enumerate(groups)]
         lds_doubles = max(1, (len(rows) + W*ring_rows)*TS)
         src = ['extern "C" __global__ void __launch_bounds__(%d)' % (64*W),
                '%s(%s)' % (name, KERNEL_PARAMS), '{',
@@ -675,7 +727,7 @@ def emit_module(prog, opts=None):
             if worst <= opts.max_live + 5 or len(con_sets) >= prog.M:
                 break
             parts += 1
-    con_groups = [(0, 0)]*len(con_sets)
+    con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
     # waves ride in the shadow of the store-bound Jacobian waves.
@@ -701,7 +753,8 @@ def emit_module(prog, opts=None):
             '#define OPTY_STORE_AUX %d' % opts.store_aux,
             '#include "opty_device.h"', '']
     source = '\n'.join(head + parts)
-    meta = dict(kernels=kernels, groups=[list(g) for g in groups],
+    meta = dict(kernels=kernels,
+                groups=[[list(rg) for rg in grp] for grp in groups],
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
                 sha=hashlib.sha256(source.encode()).hexdigest())

@@ -183,9 +183,10 @@ def test_group_ranges_cover_block():
     col = ConstraintCollocator(**problems.build('pend3_link_midpoint_small'))
     prog = col._build_program()
     for opts in (EmitOptions(), EmitOptions(chunk=8, groups=3),
-                 EmitOptions(chunk=2, groups=100)):
+                 EmitOptions(interleave=0), EmitOptions(chunk=2, groups=100)):
         _, meta = emit_module(prog, opts)
-        g = meta['groups']
+        # strips of all waves, in block order, tile the block
+        g = sorted(rg for grp in meta['groups'] for rg in grp)
         assert g[0][0] == 0 and g[-1][1] == prog.P
         assert all(a[1] == b[0] for a, b in zip(g, g[1:]))
         assert all(a[0] % 2 == 0 for a in g)

@@ -80,16 +80,19 @@ def model_flush(calls, P, b0, nvalid, R):
 
 
 def parse_groups(source, kernel='opty_jac'):
-    """Per group: ordered list of tile writes and flush calls, recovered from
-    the generated HIP text."""
+    """Per wave group: one ordered list of tile writes and flush calls per
+    entry strip, recovered from the generated HIP text."""
     body = source[source.index('\n%s(' % kernel):]
     body = body[:body.index('\n}\n')]
     groups, cur = [], None
     for line in body.splitlines():
         line = line.strip()
-        if line.startswith('case ') or cur is None and 'const int b0' in line:
+        if line.startswith('case ') or not groups and 'const int b0' in line:
+            groups.append([])
+            cur = None
+        if line.startswith('// strip '):
             cur = []
-            groups.append(cur)
+            groups[-1].append(cur)
         m = re.match(r'ring\[(\d+) \+ lane\] = ', line)
         if m and cur is not None:
             cur.append(('write_slot', int(m.group(1))//TS))
@@ -105,14 +108,16 @@ def parse_groups(source, kernel='opty_jac'):
     return [g for g in groups if g]
 
 
-@pytest.mark.parametrize('chunk,groups', [(16, None), (32, 1), (32, 3),
-                                          (64, 4), (16, 7)])
+@pytest.mark.parametrize('chunk,groups,interleave', [
+    (16, None, 1), (32, 1, 1), (32, 3, 1), (64, 4, 0), (16, 7, 1),
+    (32, None, 0), (32, 6, 0)])
 @pytest.mark.parametrize('name', ['config3_10link_small',
                                   'pend3_link_midpoint_small'])
-def test_every_element_written_once(name, chunk, groups):
+def test_every_element_written_once(name, chunk, groups, interleave):
     col = ConstraintCollocator(**problems.build(name))
     prog = col._build_program()
-    opts = EmitOptions(chunk=chunk, groups=groups, ablate='store_only')
+    opts = EmitOptions(chunk=chunk, groups=groups, ablate='store_only',
+                       interleave=interleave)
     source, meta = emit_module(prog, opts)
     P = prog.P
     R = chunk + 16
@@ -122,7 +127,10 @@ def test_every_element_written_once(name, chunk, groups):
         for nvalid in (64, 1, 37):
             stores = {}
             full_lines = 0
-            for (e0, e1), calls in zip(meta['groups'], parsed):
+            strips = [(rg, calls) for grp, pg in zip(meta['groups'], parsed)
+                      for rg, calls in zip(grp, pg)]
+            assert sum(len(g) for g in parsed) == len(strips)
+            for (e0, e1), calls in strips:
                 # rebuild virtual entries from the write order
                 seq, v = [], e0
                 for c in calls:
