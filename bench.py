@@ -106,11 +106,22 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # Development aid: OPTY_BENCH_OVERSUBSCRIBE=1 lets several ranks share one
+    # GPU (gloo rendezvous; RCCL refuses duplicate devices) so that the
+    # multi-process launch path can be exercised on a 1-GPU box.  The result
+    # is flagged in `config` and is not a scaling measurement.
+    oversub = os.environ.get('OPTY_BENCH_OVERSUBSCRIBE') == '1' and \
+        world > torch.cuda.device_count()
+    if oversub:
+        local_rank %= torch.cuda.device_count()
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, 'launch with torch.distributed.run'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(
-            'cuda', local_rank))
+        if oversub:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device(
+                'cuda', local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -194,8 +205,11 @@ def main():
         # prescribes; summaries under profiles/)
         traffic = None
         try:
-            with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
-                traffic = json.load(f)[dom]['hbm_bytes_per_launch']
+            # the counters were collected on the 100 000-node launch
+            if N == 100000:
+                with open(os.path.join(REPO, 'profiles',
+                                       'traffic.json')) as f:
+                    traffic = json.load(f)[dom]['hbm_bytes_per_launch']
         except (OSError, KeyError, ValueError):
             pass
         # weak scaling: every rank evaluates a full N-node problem per step;
@@ -222,6 +236,7 @@ def main():
                             'outputs left distributed' +
                             (', + RCCL all-gather of con and jac'
                              if gathered is not None else ''),
+                'oversubscribed': bool(oversub),
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
                 'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
