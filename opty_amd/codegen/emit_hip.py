@@ -59,7 +59,7 @@ class EmitOptions(object):
     """
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
-                 flush_unroll=4, waves=1, store_aux=18, con_rows_per_wave=0,
+                 flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
                  interleave=0):
         # 1: every wave gets a cheap strip and an expensive strip of the
         # block (see _ModuleWriter.group_ranges); measured slower than one
@@ -74,7 +74,9 @@ class EmitOptions(object):
         # opty_conjac (profiles/r01_tuning.txt)
         self.store_aux = int(store_aux)
         self.flush_unroll = int(flush_unroll)
-        self.waves = int(waves)      # waves per workgroup (share the slab)
+        # waves per workgroup (they share one input slab); None: as many as
+        # it takes to keep 4+ waves resident per CU within its 160 KB of LDS
+        self.waves = None if waves is None else int(waves)
         self.chunk = int(chunk)
         assert self.chunk % 2 == 0 and self.chunk >= 2
         assert self.chunk < 16 or self.chunk in (16, 32, 64), \
@@ -86,12 +88,13 @@ class EmitOptions(object):
         # profiling aids (never used by the product): 'store_only' writes a
         # lane-dependent dummy instead of evaluating the expressions,
         # 'compute_only' predicates every flush store off
-        assert ablate in (None, 'store_only', 'compute_only')
+        assert ablate in (None, 'store_only', 'compute_only', 'only_cheap',
+                          'only_dear')
         self.ablate = ablate
 
     def key(self):
         return ('chunk=%d groups=%s max_live=%d ablate=%s flush_unroll=%d '
-                'waves=%d store_aux=%d con_rows_per_wave=%d interleave=%d' % (
+                'waves=%s store_aux=%d con_rows_per_wave=%d interleave=%d' % (
                     self.chunk, self.groups, self.max_live, self.ablate,
                     self.flush_unroll, self.waves, self.store_aux,
                     self.con_rows_per_wave, self.interleave))
@@ -616,12 +619,22 @@ class _ModuleWriter(object):
         workgroup is ``W`` consecutive groups of one 64-node block: they share
         one input slab (filled cooperatively) and each owns a ring tile."""
         G = len(groups)
-        W = max(1, min(W, G))
-        sets = (G + W - 1)//W
-        rows = self._kernel_rows(groups, con_of_group)
+        keep = [True]*G
+        if self.o.ablate in ('only_cheap', 'only_dear'):
+            cheap = [sum(self._strip_cost(*rg) for rg in grp if rg[1] > rg[0])
+                     <= 16 and not con_of_group[g]
+                     for g, grp in enumerate(groups)]
+            keep = [c == (self.o.ablate == 'only_cheap') for c in cheap]
+        rows = self._kernel_rows([g for g, k in zip(groups, keep) if k],
+                                 [c for c, k in zip(con_of_group, keep) if k])
         slab_of = {r: k for k, r in enumerate(rows)}
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
+        if W is None:
+            W = self._waves_per_workgroup(len(rows), ring_rows)
+        W = max(1, min(W, G))
+        sets = (G + W - 1)//W
         bodies = [self._group_body(grp, con_of_group[g], slab_of)
+                  if keep[g] else []
                   for g, grp in enumerate(groups)]
         lds_doubles = max(1, (len(rows) + W*ring_rows)*TS)
         src = ['extern "C" __global__ void __launch_bounds__(%d)' % (64*W),
@@ -644,6 +657,23 @@ class _ModuleWriter(object):
         return '\n'.join(src), dict(name=name, groups=G, waves_per_wg=W,
                                     wgs_per_block=sets,
                                     lds_bytes=lds_doubles*8)
+
+    @staticmethod
+    def _waves_per_workgroup(slab_rows, ring_rows, lds_per_cu=160*1024):
+        """A workgroup holds one input slab and one ring tile per wave; the
+        CU's 160 KB of LDS bound how many workgroups are resident.  A
+        50-state system (27 KB slab + 25 KB ring) fits three single-wave
+        workgroups per CU -- one SIMD idles -- but two two-wave workgroups.
+        Returns the smallest width that keeps a wave on each of the CU's four
+        SIMDs (kernels this large rarely fit a second wave's registers), or
+        else the one with most resident waves."""
+        best, best_w = 0, 1
+        for W in (1, 2, 3, 4):
+            lds = max(1, (slab_rows + W*ring_rows)*TS)*8
+            waves = min(4, (lds_per_cu//lds)*W)
+            if waves > best:
+                best, best_w = waves, W
+        return best_w
 
     def uniform_kernel(self):
         """Must be printed after every kernel that allocates ``uni`` slots."""
