@@ -89,7 +89,7 @@ class EmitOptions(object):
         # lane-dependent dummy instead of evaluating the expressions,
         # 'compute_only' predicates every flush store off
         assert ablate in (None, 'store_only', 'compute_only', 'only_cheap',
-                          'only_dear')
+                          'only_dear', 'uni_lit', 'uni_free')
         self.ablate = ablate
 
     def key(self):
@@ -475,6 +475,13 @@ class _ModuleWriter(object):
                 off = p.cur_offset if kind == 'cur' else p.adj_offset
                 return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
             if self._uniform_leaf(i):
+                # diagnostics (wrong values): what would the kernel cost if
+                # node-invariant operands were literals / free?
+                if self.o.ablate == 'uni_lit':
+                    return _lit(1.0 + 1.0/(3.0 + self._slot(i)))
+                if self.o.ablate == 'uni_free':
+                    self._slot(i)
+                    return 'h'
                 return 'uni_c[%d]' % self._slot(i)
             return None
 
