@@ -211,6 +211,39 @@ def implicit_known_trajectory(num_nodes=40, method='backward euler',
                 integration_method=method)
 
 
+def elementary_functions(num_nodes=45, method='backward euler',
+                         variable_duration=False):
+    """Not from the reference's examples: a 4-state system that exercises
+    every elementary function the C99 printer of ``ufuncify_matrix``
+    (``opty/utils.py:748-757``) can meet in practice -- tanh, exp, sqrt, atan,
+    log, sinh, cosh, tan, pow with a non-integer exponent, asin, acos, atan2
+    and a division by an expression -- with a known trajectory, an unknown
+    input, a known non-integer exponent and an unknown parameter."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    a, b, c, hh = sm.symbols('a, b, c, h', real=True)
+    x, y, z, w, u, k = me.dynamicsymbols('x, y, z, w, u, k', real=True)
+    eom = sm.Matrix([
+        x.diff() - (sm.tanh(y) + sm.exp(-x**2)*u + sm.sqrt(1 + z**2)),
+        y.diff() - (sm.atan(x*z) + sm.log(1 + w**2)*a - sm.sinh(x/2)),
+        z.diff() - (sm.cosh(3*y/10)*sm.tan(w/2) + (sm.Rational(3, 2) + x)**b
+                    - k/(1 + y**2)),
+        w.diff() - (sm.asin(sm.tanh(z)/2) + sm.acos(x/2)*c
+                    + sm.atan2(y, 2 + z)),
+    ])
+    N = num_nodes
+    interval = hh if variable_duration else 0.05
+    dur = (N - 1)*(hh if variable_duration else 0.05)
+    inst = (x.func(0*hh if variable_duration else 0.0) - 0.25,
+            w.func(dur)**2 - 0.5)
+    return dict(equations_of_motion=eom, state_symbols=(x, y, z, w),
+                num_collocation_nodes=N, node_time_interval=interval,
+                known_parameter_map={b: 1.7, c: 0.8},
+                known_trajectory_map={k: np.cos(np.linspace(0.0, 3.0, N))},
+                instance_constraints=inst, time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -240,6 +273,10 @@ CONFIGS = {
     'implicit_traj_mid_small': (implicit_known_trajectory,
                                 {'num_nodes': 33, 'method': 'midpoint',
                                  'variable_duration': False}),
+    'elementary_be_small': (elementary_functions, {}),
+    'elementary_mid_small': (elementary_functions,
+                             {'num_nodes': 70, 'method': 'midpoint',
+                              'variable_duration': True}),
     'config5_standin_24link': (n_link_cart_pendulum,
                                {'num_links': 24, 'num_nodes': 50000,
                                 'variable_duration': True}),
