@@ -57,6 +57,9 @@ enum { OPTY_HIP_HOST = 0, OPTY_HIP_DEVICE = 1 };
 enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
        OPTY_HIP_EVAL_FUSED = 3 };
 
+#define OPTY_HIP_LAYOUT_COO 0
+#define OPTY_HIP_LAYOUT_CSR 1
+
 typedef struct opty_hip_desc {
     int64_t N;            /* collocation (time) nodes                        */
     int32_t n;            /* states                                          */
@@ -80,6 +83,10 @@ typedef struct opty_hip_desc {
     int32_t num_uniform;  /* entries of the node-invariant table (opty_uni)  */
     int32_t uniform_dynamic; /* 1 if that table depends on `free` (r+s > 0)  */
     int32_t device;       /* HIP device ordinal                              */
+    int32_t layout;       /* OPTY_HIP_LAYOUT_COO: the reference's node-major
+                             order jac[i*P + e]; OPTY_HIP_LAYOUT_CSR: sorted by
+                             row then column, jac[S_j*(N-1) + i*L_j + pos]
+                             (needs opty_hip_set_block_pattern)              */
 } opty_hip_desc;
 
 /* Loads the code object and allocates the device-side state (known
@@ -108,7 +115,9 @@ int opty_hip_set_instance_indices(opty_hip_problem *p,
                                   const int64_t *atom_free_index,
                                   const int64_t *rows, const int64_t *cols);
 
-/* Pruned blocks only (P < M*C): (j, k) of every stored entry, 2*P int32. */
+/* Pruned blocks (P < M*C) and the CSR layout: (j, k) of every stored entry
+ * of a block in storage order, 2*P int32 (CSR: grouped by j, ascending
+ * column within a row). */
 int opty_hip_set_block_pattern(opty_hip_problem *p, const int32_t *jk);
 
 int64_t opty_hip_num_free(const opty_hip_problem *p);

@@ -39,6 +39,9 @@ from . import ir
 WAVE = 64
 TS = 65
 LINE_MODE_MIN_P = 64
+#: csr layout: rows up to this many entries are staged whole and written
+#: as one contiguous span per wave (tile = 65*8 bytes per entry)
+CSR_MAX_ROW = 64
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -356,14 +359,34 @@ class _ModuleWriter(object):
         raise AssertionError(kind)
 
     # -- grouping --------------------------------------------------------------
+    def csr(self):
+        return getattr(self.p, 'layout', 'coo') == 'csr'
+
+    def _row_of(self, e):
+        """Equation whose row holds stored entry ``e`` (csr layout)."""
+        rs = self.p.row_start
+        j = 0
+        while rs[j + 1] <= e:
+            j += 1
+        return j
+
     def _chunks(self, e0, e1):
         K = self.o.chunk
+        if self.csr():
+            # never across a row; a row that fits the tile is one chunk
+            out, rs = [], self.p.row_start
+            for j in range(self.p.M):
+                a, b = max(e0, rs[j]), min(e1, rs[j + 1])
+                step = CSR_MAX_ROW if b - a <= CSR_MAX_ROW else K
+                out += [(c, min(c + step, b)) for c in range(a, b, step)]
+            return out
         return [(c, min(c + K, e1)) for c in range(e0, e1, K)]
 
     def line_mode(self):
         """Line-aligned ring flush (see opty_device.h) for all but tiny
         blocks; needs the chunk width to be a multiple of a 16-double line."""
-        return self.p.P >= LINE_MODE_MIN_P and self.o.chunk % 16 == 0
+        return self.p.P >= LINE_MODE_MIN_P and self.o.chunk % 16 == 0 \
+            and not self.csr()
 
     def _virtual_end(self, e1):
         """Waves evaluate 15 entries past their range so that they own whole
@@ -393,8 +416,22 @@ class _ModuleWriter(object):
         unit = 16 if self.line_mode() else K
         nunits = max(1, P//unit if self.line_mode() else (P + K - 1)//K)
         two = bool(self.o.interleave) and self.line_mode()
+        if self.csr():
+            # strips are whole rows: cut where a row starts
+            starts = sorted(set(self.p.row_start[:-1]) - {P})
+            nunits = max(1, len(starts))
 
         def cut(S):
+            if self.csr():
+                # the row start nearest to an even share of the entries
+                b = [0]
+                for g in range(1, S):
+                    rest = [x for x in starts if x > b[-1]]
+                    keep = S - g - 1        # starts the later waves need
+                    rest = rest[:len(rest) - keep] if keep else rest
+                    b.append(min(rest, key=lambda x: abs(x - g*P/S)))
+                b.append(P)
+                return [(b[g], b[g + 1]) for g in range(S)]
             b = [((g*nunits)//S)*unit for g in range(S)] + [P]
             return [(b[g], b[g + 1]) for g in range(S)]
 
@@ -452,6 +489,9 @@ class _ModuleWriter(object):
             return 0
         if self.line_mode():
             return K + 16
+        if self.csr():
+            return max(b - a for e0, e1 in grp
+                       for a, b in self._chunks(e0, e1))
         return min(K, width)
 
     def _group_body(self, grp, con_rows, slab_of):
@@ -506,6 +546,8 @@ class _ModuleWriter(object):
             body.lines.append('// strip %d %d' % (e0, e1))
             if self.line_mode():
                 self._strip_lines(body, e0, e1, value, nv, R)
+            elif self.csr():
+                self._strip_csr(body, e0, e1, value, nv)
             else:
                 self._strip_simple(body, e0, e1, value, nv)
         body.end_scope()
@@ -536,6 +578,31 @@ class _ModuleWriter(object):
                 if self.o.ablate != 'compute_only':
                     body.lines.append('opty_head_piece<%d>(ring, jrow, '
                                       '%d, b0, lane);' % (R, p.P))
+            body.lines.append('opty_wave_sync();')
+
+    def _strip_csr(self, body, e0, e1, value, nv):
+        """Row-sorted layout: equation j's L entries of the wave's 64 nodes
+        are one contiguous span ``jac[S_j*ncn + i*L + pos]`` (``S_j`` entries
+        precede row j in a block, ``ncn`` constraint nodes in this launch).
+        Rows up to CSR_MAX_ROW entries are staged whole and written front to
+        back (opty_flush_flat); wider rows go out in chunk-wide pieces."""
+        p = self.p
+        for c0, c1 in self._chunks(e0, e1):
+            j = self._row_of(c0)
+            S, L = p.row_start[j], p.row_start[j + 1] - p.row_start[j]
+            body.new_scope()
+            for e in range(c0, c1):
+                body.begin_entry()
+                body.lines.append('ring[%d + lane] = %s;'
+                                  % ((e - c0)*TS, value(e)))
+            body.lines.append('opty_wave_sync();')
+            dst = 'jac + %dLL*ncn + nloc*%dLL' % (S, L)
+            if c0 == S and c1 == S + L:
+                body.lines.append('opty_flush_flat<%d>(ring, %s, %s, lane);'
+                                  % (L, dst, nv))
+            else:
+                body.lines.append('opty_flush8<%d>(ring, %s + %d, %dLL, %s, '
+                                  'lane);' % (c1 - c0, dst, c0 - S, L, nv))
             body.lines.append('opty_wave_sync();')
 
     def _strip_simple(self, body, e0, e1, value, nv):
@@ -615,9 +682,11 @@ class _ModuleWriter(object):
     const bool valid = node < node_end;
     const long long rem = node_end - node0;
     const int nvalid = rem < 64 ? (int)rem : 64;
-    double *jrow = jac + (node0 - node_begin)*{P}LL;
+    const long long ncn = node_end - node_begin, nloc = node0 - node_begin;
+    double *jrow = jac + nloc*{P}LL;
     double *const ring = lds + {slab} + wave*{ring};
     (void)valid; (void)jrow; (void)nvalid; (void)node; (void)ring; (void)grp;
+    (void)ncn;
 '''
 
     def kernel(self, name, groups, con_of_group, W=1):
@@ -793,6 +862,7 @@ def emit_module(prog, opts=None):
     meta = dict(kernels=kernels,
                 groups=[[list(rg) for rg in grp] for grp in groups],
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
+                layout=getattr(prog, 'layout', 'coo'),
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
                 sha=hashlib.sha256(source.encode()).hexdigest())
     return source, meta

@@ -17,6 +17,10 @@ from .lower import Lowerer, forward_jacobian
 class CollocationProgram(object):
     """Plain data; consumed by :mod:`opty_amd.codegen.emit_hip`.
 
+    ``layout``: 'coo' or 'csr'; ``row_start[j]`` = first stored entry of
+    equation j in ``jac_out`` when the entries are grouped by row (always true
+    for 'csr' and for the unpruned 'coo' block).
+
     Attributes
     ----------
     dag : ir.DAG
@@ -46,7 +50,7 @@ class CollocationProgram(object):
 def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
                   num_known_traj, parameters, num_known_par, h_sym,
                   variable_duration, wrt, method, instance=None,
-                  implicit=(), prune_zeros=False):
+                  implicit=(), prune_zeros=False, layout='coo'):
     """Lowers the discretised equations and differentiates them.
 
     Parameters mirror the reference's locals: ``state_cur``/``state_adj`` are
@@ -60,6 +64,12 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
     ``kd`` (``opty/direct_collocation.py:2080-2093``): its discrete symbol is an
     applied function ``r_i(x_i)``, lowered as a plain input row that carries a
     chain-rule link for the Jacobian.
+
+    ``layout``: ``'coo'`` stores the values in the reference's order (node
+    major, ``opty/direct_collocation.py:2644-2675``); ``'csr'`` stores them
+    sorted by constraint row, then column -- equation-major rows
+    ``j*(N-1) + i``, each row's entries in ascending free index -- the order a
+    compressed-sparse-row consumer needs (opt-in: changes the index contract).
 
     ``instance``: optional ``(expressions, atom_symbols, known_par_syms)`` --
     instance constraints written over one placeholder Symbol per function
@@ -103,7 +113,20 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
     # zero.
     pattern = [(j, k) for j, row in enumerate(jac) for k, node in
                enumerate(row) if not (prune_zeros and node == dag.zero)]
+    if layout == 'csr':
+        # the column of wrt entry k of node i is monotone in this key for
+        # every i (N >= 2): states interleave adjacent/current, then inputs,
+        # then the parameter tail
+        key = _column_key(n, q, method)
+        pattern.sort(key=lambda jk: (jk[0], key(jk[1])))
+    elif layout != 'coo':
+        raise ValueError('layout must be "coo" or "csr".')
     jac_out = [jac[j][k] for j, k in pattern]
+    row_start = [0]*(len(con_out) + 1)
+    for j, _ in pattern:
+        row_start[j + 1] += 1
+    for j in range(len(con_out)):
+        row_start[j + 1] += row_start[j]
 
     # row r of the slab: states then unknown inputs come from `free`
     # (``free`` viewed as (n+q, N), opty/utils.py:308-318); known inputs from
@@ -139,4 +162,31 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
         adj_offset=0 if method == 'backward euler' else 1,
         inst_con_out=inst_con_out, inst_jac_out=inst_jac_out,
         num_inst_atoms=num_atoms, pattern=pattern,
-        pruned=bool(prune_zeros))
+        pruned=bool(prune_zeros), layout=layout, row_start=row_start)
+
+
+def _column_key(n, q, method):
+    """Sort key of wrt index k equal to the order of the free-vector column
+    it differentiates with respect to (the closed form of
+    ``opty/direct_collocation.py:2657-2675`` at a generic node)."""
+    big = 1 << 20           # stands for N; node i = 1
+
+    def key(k):
+        if method == 'backward euler':
+            if k < n:
+                return k*big + 2
+            if k < 2*n:
+                return (k - n)*big + 1
+            if k < 2*n + q:
+                return (n + k - 2*n)*big + 2
+            return (n + q)*big + (k - 2*n - q)
+        if k < n:
+            return k*big + 1
+        if k < 2*n:
+            return (k - n)*big + 2
+        if k < 2*n + q:
+            return (n + k - 2*n)*big + 1
+        if k < 2*n + 2*q:
+            return (n + k - 2*n - q)*big + 2
+        return (n + q)*big + (k - 2*n - 2*q)
+    return key

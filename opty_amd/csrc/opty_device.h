@@ -99,6 +99,44 @@ __device__ __forceinline__ void opty_flush8(const double *tile, double *out,
 }
 
 // ---------------------------------------------------------------------------
+// Row-sorted ("csr") layout: the L entries of equation j of 64 consecutive
+// nodes are ONE contiguous span of 64*L doubles, dst[nd*L + k].  The tile holds
+// them entry-major ([k][nd]); the wave sweeps the span front to back, every
+// lane storing one 16-byte aligned pair per step, i.e. 1 KB of consecutive
+// bytes per store instruction and whole 128-byte lines everywhere but at the
+// two ends of the span.
+// ---------------------------------------------------------------------------
+template <int L>
+__device__ __forceinline__ void opty_flush_flat(const double *tile,
+                                                double *dst, int nvalid,
+                                                int lane) {
+    const int total = nvalid*L;
+    // pairs are 16-byte aligned in memory: when dst is 8 (mod 16) the first
+    // pair is (-1, 0) and only its second half exists
+    const int phase = (int)((reinterpret_cast<unsigned long long>(dst) >> 3) & 1);
+    typedef double opty_d2 __attribute__((ext_vector_type(2)));
+    constexpr int STEPS = (OPTY_WAVE*L + 1 + 2*OPTY_WAVE - 1)/(2*OPTY_WAVE);
+#pragma unroll 4
+    for (int it = 0; it < STEPS; ++it) {
+        const int f = 2*(it*OPTY_WAVE + lane) - phase;
+        if (f >= total) break;
+        const int f1 = f + 1;
+        const int n0 = f >= 0 ? f/L : 0, n1 = f1/L;
+        const int k0 = f - n0*L, k1 = f1 - n1*L;
+        if (f >= 0 && f1 < total) {
+            opty_d2 v;
+            v.x = tile[k0*OPTY_TS + n0];
+            v.y = tile[k1*OPTY_TS + n1];
+            __builtin_nontemporal_store(v, reinterpret_cast<opty_d2 *>(dst + f));
+        } else if (f >= 0) {
+            __builtin_nontemporal_store(tile[k0*OPTY_TS + n0], dst + f);
+        } else if (f1 < total) {
+            __builtin_nontemporal_store(tile[k1*OPTY_TS + n1], dst + f1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Line-aligned flush (blocks with P >= 64).
 //
 // Measured on MI355X (tools/store_bench.hip): streaming stores that cover whole

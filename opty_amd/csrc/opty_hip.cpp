@@ -70,6 +70,7 @@ struct IndexDims {
     int n, q, M, C, tail, method;
     int P;                 // stored entries per node block
     const int *pattern;    // (j, k) per stored entry, or null: e -> (e/C, e%C)
+    const int *rowinfo;    // CSR layout: (S_j, L_j) per stored entry, or null
 };
 
 __device__ __forceinline__ void index_of(const IndexDims &d, long long i,
@@ -116,8 +117,17 @@ opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
             }
             long long row, col;
             index_of(d, i + d.offset, j, k, row, col);
-            r[e] = row;
-            c[e] = col;
+            if (d.rowinfo) {
+                // row-sorted layout: S entries of a block precede row j,
+                // the row holds L of them
+                const long long S = d.rowinfo[2*e], L = d.rowinfo[2*e + 1];
+                const long long dst = S*d.count + i*L + (e - S);
+                rows[dst] = row;
+                cols[dst] = col;
+            } else {
+                r[e] = row;
+                c[e] = col;
+            }
         }
     }
 }
@@ -135,6 +145,7 @@ struct opty_hip_problem {
     long long *d_inst_idx = nullptr, *d_inst_rows = nullptr,
               *d_inst_cols = nullptr;
     int *d_pattern = nullptr;   // (j, k) per stored block entry when pruned
+    int *d_rowinfo = nullptr;   // (S_j, L_j) per stored block entry (CSR)
     double *d_free = nullptr, *d_con = nullptr, *d_jac = nullptr;  // staging
     long long *d_rows = nullptr, *d_cols = nullptr;                // staging
     double h = 0.0;
@@ -424,6 +435,9 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
     if (desc->P < 0 || desc->P > desc->M*desc->C)
         return fail("P = %d stored entries per block, block is %d x %d",
                     desc->P, desc->M, desc->C);
+    if (desc->layout != OPTY_HIP_LAYOUT_COO &&
+        desc->layout != OPTY_HIP_LAYOUT_CSR)
+        return fail("bad layout %d", desc->layout);
     if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
         desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1 ||
         desc->con_wgs_per_block < 1)
@@ -482,7 +496,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
     if (!p) return 0;
     (void)hipSetDevice(p->d.device);
     (void)hipStreamSynchronize(p->stream);
-    void *bufs[] = {p->d_pattern, p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
+    void *bufs[] = {p->d_pattern, p->d_rowinfo, p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
                     p->d_cols};
     for (void *b : bufs)
@@ -588,6 +602,23 @@ int opty_hip_set_block_pattern(opty_hip_problem *p, const int32_t *jk) {
     if (int rc = ensure(&p->d_pattern, (size_t)2*p->d.P)) return rc;
     HIP_TRY(hipMemcpy(p->d_pattern, jk, 2*p->d.P*sizeof(int32_t),
                       hipMemcpyHostToDevice));
+    if (p->d.layout == OPTY_HIP_LAYOUT_CSR) {
+        std::vector<int32_t> info(2*(size_t)p->d.P);
+        for (int e = 0; e < p->d.P;) {
+            int e1 = e;
+            while (e1 < p->d.P && jk[2*e1] == jk[2*e]) ++e1;
+            if (e > 0 && jk[2*e] <= jk[2*(e - 1)])
+                return fail("CSR block pattern is not grouped by row");
+            for (int t = e; t < e1; ++t) {
+                info[2*t] = e;
+                info[2*t + 1] = e1 - e;
+            }
+            e = e1;
+        }
+        if (int rc = ensure(&p->d_rowinfo, info.size())) return rc;
+        HIP_TRY(hipMemcpy(p->d_rowinfo, info.data(),
+                          info.size()*sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -649,6 +680,12 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     d.method = p->d.method;
     d.P = p->d.P;
     d.pattern = p->d_pattern;
+    d.rowinfo = p->d.layout == OPTY_HIP_LAYOUT_CSR ? p->d_rowinfo : nullptr;
+    if (p->d.layout == OPTY_HIP_LAYOUT_CSR && !p->d_rowinfo)
+        return fail("the CSR block pattern was never set "
+                    "(opty_hip_set_block_pattern)");
+    if (p->d.layout == OPTY_HIP_LAYOUT_CSR && node_offset != 0)
+        return fail("the CSR layout is not node-sharded");
     if (p->d.P != p->d.M*p->d.C && !p->d_pattern)
         return fail("the block pattern was never set "
                     "(opty_hip_set_block_pattern)");

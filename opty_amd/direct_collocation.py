@@ -47,6 +47,8 @@ class ConstraintCollocator(object):
     * ``parallel`` is accepted and ignored (a GPU launch is always parallel);
     * ``tmp_dir`` is the code-object cache directory;
     * extra keywords ``device`` (HIP ordinal), ``emit_options`` and
+      ``jacobian_layout='csr'``: opt-in, stores the Jacobian values sorted by
+      row then column (see ``jacobian_csr_structure``);
       ``prune_zeros``: opt-in, drops the structurally zero entries of the
       per-node block from ``jacobian(free)`` / ``jacobian_indices()`` (the
       reference keeps them, ``opty/direct_collocation.py:2589-2593``; 61 % of
@@ -63,8 +65,12 @@ class ConstraintCollocator(object):
                  instance_constraints=None, time_symbol=None, tmp_dir=None,
                  integration_method='backward euler', parallel=False,
                  show_compile_output=False, backend='hip', device=0,
-                 emit_options=None, prune_zeros=False):
+                 emit_options=None, prune_zeros=False,
+                 jacobian_layout='coo'):
         self._prune_zeros = bool(prune_zeros)
+        if jacobian_layout not in ('coo', 'csr'):
+            raise ValueError('jacobian_layout must be "coo" or "csr".')
+        self._jacobian_layout = jacobian_layout
         self._eom = sm.ImmutableDenseMatrix(equations_of_motion)
         if self._eom.shape[1] != 1:
             raise ValueError('equations_of_motion must be a column matrix.')
@@ -506,7 +512,8 @@ class ConstraintCollocator(object):
             self.parameters, self.num_known_parameters,
             self.time_interval_symbol, self._variable_duration,
             self._wrt(), self.integration_method, instance,
-            implicit=self._implicit_chain(), prune_zeros=self._prune_zeros)
+            implicit=self._implicit_chain(), prune_zeros=self._prune_zeros,
+            layout=self._jacobian_layout)
         return self._program
 
     def generate_source(self):
@@ -532,7 +539,8 @@ class ConstraintCollocator(object):
             con_wgs_per_block=meta['kernels']['con']['wgs_per_block'],
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
-            device=self._device)
+            device=self._device,
+            layout=1 if self._jacobian_layout == 'csr' else 0)
 
     def _known_trajectory_array(self, free):
         vals = []
@@ -559,7 +567,7 @@ class ConstraintCollocator(object):
             callable(v) for v in self.known_trajectory_map.values())
         if self.num_known_input_trajectories and not self._callable_known:
             hip.set_known_trajectories(self._known_trajectory_array(None))
-        if self._program.pruned:
+        if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
         if self.num_instance_constraints:
             idx = self.instance_constraints_free_index_map
@@ -631,6 +639,34 @@ class ConstraintCollocator(object):
         cols = np.empty(hip.nnz, dtype=np.int64)
         hip.jacobian_indices(rows, cols, hb.HOST)
         return rows, cols
+
+    def jacobian_csr_structure(self):
+        """``(row_ptr, col_idx)`` (int64) of the constraint Jacobian in
+        compressed-sparse-row form, for ``jacobian_layout='csr'``: the values
+        ``generate_jacobian_function`` returns are then ``data`` of
+        ``scipy.sparse.csr_matrix((data, col_idx, row_ptr))`` as they are.
+        Rows are the reference's constraint order (``j*(N-1) + i``, then the
+        instance constraints), columns ascend within a row."""
+        if self._jacobian_layout != 'csr':
+            raise ValueError("jacobian_csr_structure needs "
+                             "jacobian_layout='csr'.")
+        prog = self._build_program()
+        ncn = self.num_collocation_nodes - 1
+        rs = np.asarray(prog.row_start, dtype=np.int64)
+        lens = np.diff(rs)
+        # row j*(N-1) + i starts at S_j*(N-1) + i*L_j
+        starts = (rs[:-1, None]*ncn +
+                  np.arange(ncn, dtype=np.int64)[None, :]*lens[:, None])
+        row_ptr = np.empty(self.num_constraints + 1, dtype=np.int64)
+        row_ptr[:self.num_eom*ncn] = starts.ravel()
+        base = prog.P*ncn
+        counts = np.bincount(self._inst_rows - self.num_eom*ncn,
+                             minlength=self.num_instance_constraints) \
+            if self.num_instance_constraints else np.zeros(0, dtype=np.int64)
+        row_ptr[self.num_eom*ncn:] = base + np.concatenate(
+            ([0], np.cumsum(counts)))
+        _, cols = self.jacobian_indices()
+        return row_ptr, cols
 
     # host helpers with the reference's names ---------------------------
     def eval_instance_constraints(self, free):

@@ -73,8 +73,14 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     os.makedirs(cache_dir, exist_ok=True)
     with open(os.path.join(CSRC, 'opty_device.h')) as f:
         header = f.read()
-    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17'] + \
-        list(extra_flags)
+    # -O2, not -O3: identical kernel times (10-link and 24-link systems), but
+    # hipcc 7.2 -O3 miscompiled one generated kernel (24-link pendulum,
+    # row-sorted layout: two entries of equation 47 came out as 1e16 at every
+    # node; -O1/-O2/-Os agree with the reference to 1e-13).  OPTY_HIPCC_OPT /
+    # OPTY_HIPCC_FLAGS override for experiments.
+    flags = ['--offload-arch=' + ARCH,
+             os.environ.get('OPTY_HIPCC_OPT', '-O2'), '-std=c++17'] + \
+        os.environ.get('OPTY_HIPCC_FLAGS', '').split() + list(extra_flags)
     digest = hashlib.sha256(
         (source + '\0' + header + '\0' + ' '.join(flags)).encode()
     ).hexdigest()[:24]
@@ -113,7 +119,7 @@ class _Desc(ctypes.Structure):
             'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'P', 'method',
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
-            'num_uniform', 'uniform_dynamic', 'device')]
+            'num_uniform', 'uniform_dynamic', 'device', 'layout')]
 
 
 class _ObjDesc(ctypes.Structure):

@@ -374,3 +374,73 @@ def test_reference_unit_test_fixtures_on_dag(name):
         r, c = col._instance_constraints_jacobian_indices()
         np.testing.assert_array_equal(r, case['rows'][-len(r):])
         np.testing.assert_array_equal(c, case['cols'][-len(c):])
+
+
+@pytest.mark.parametrize('name,prune', [
+    ('config3_10link_small', False), ('config3_10link_small', True),
+    ('pend3_link_midpoint_small', False),
+    ('pend2_link_vardur_unkmass_small', True),
+    ('elementary_mid_small', False), ('chaplygin_mid_small', True),
+    ('one_eom_be_small', False)])
+def test_csr_layout_program_order(name, prune):
+    """``jacobian_layout='csr'``: the stored entries of a block are grouped
+    by equation and ascend in the reference's column index
+    (``jacobian_indices``, golden) at every node; the values are the
+    reference's values, re-ordered."""
+    meta, z = gu.load(name)
+    col = ConstraintCollocator(jacobian_layout='csr', prune_zeros=prune,
+                               **problems.build(name))
+    prog = col._build_program()
+    N, C, P = meta['N'], meta['C'], meta['M']*meta['C']
+    assert prog.layout == 'csr' and prog.P == len(prog.pattern)
+    assert [j for j, _ in prog.pattern] == sorted(j for j, _ in prog.pattern)
+    for j in range(prog.M):
+        a, b = prog.row_start[j], prog.row_start[j + 1]
+        assert all(jj == j for jj, _ in prog.pattern[a:b])
+    gcols = z['cols'][:P*(N - 1)].reshape(N - 1, P)
+    sel = [j*C + k for j, k in prog.pattern]
+    for i in (0, N - 2):
+        c = gcols[i, sel]
+        for j in range(prog.M):
+            row = c[prog.row_start[j]:prog.row_start[j + 1]]
+            assert np.all(np.diff(row) > 0), (i, j, row)
+    _, jac = dag_interp.evaluate_collocator(col, z['free'])
+    full = z['jac'][:P*(N - 1)].reshape(N - 1, P)
+    gu.assert_close(jac[:prog.P*(N - 1)].reshape(N - 1, prog.P),
+                    full[:, sel], 1e-10, what='csr values')
+    if prune:
+        assert not full[:, sorted(set(range(P)) - set(sel))].any()
+
+
+@pytest.mark.parametrize('L', [1, 2, 3, 7, 16, 45, 64])
+def test_flat_flush_model(L):
+    """Python model of ``opty_flush_flat`` (opty_amd/csrc/opty_device.h):
+    every element of the span is written exactly once, from the right
+    (entry, node) of the tile, with 16-byte aligned pairs, for both
+    alignments of the span and ragged node counts."""
+    steps = (64*L + 1 + 127)//128
+    for phase in (0, 1):
+        for nvalid in (64, 1, 37):
+            total = nvalid*L
+            written = {}
+            for it in range(steps):
+                for lane in range(64):
+                    f = 2*(it*64 + lane) - phase
+                    if f >= total:
+                        continue
+                    f1 = f + 1
+                    if f >= 0 and f1 < total:
+                        assert (f + phase) % 2 == 0     # 16-byte aligned
+                        todo = (f, f1)
+                    elif f >= 0:
+                        todo = (f,)
+                    elif f1 < total:
+                        todo = (f1,)
+                    else:
+                        todo = ()
+                    for g in todo:
+                        assert g not in written
+                        written[g] = (g % L, g//L)       # tile[k][node]
+            assert sorted(written) == list(range(total))
+            for g, (k, nd) in written.items():
+                assert g == nd*L + k and nd < nvalid

@@ -18,6 +18,11 @@ from opty_amd import problems, hip_backend as hb              # noqa: E402
 from opty_amd.codegen.emit_hip import EmitOptions             # noqa: E402
 
 
+#: OPTY_TUNE_LAYOUT=csr / OPTY_TUNE_PRUNE=1 select the opt-in output layouts
+LAYOUT = os.environ.get('OPTY_TUNE_LAYOUT', 'coo')
+PRUNE = os.environ.get('OPTY_TUNE_PRUNE') == '1'
+
+
 def parse(spec):
     kw = {}
     for item in filter(None, spec.split(',')):
@@ -38,7 +43,9 @@ def main():
     for spec in specs:
         opts = EmitOptions() if spec == 'default' else parse(spec)
         t0 = time.time()
-        col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
+        col = opty_amd.ConstraintCollocator(
+            emit_options=opts, prune_zeros=PRUNE, jacobian_layout=LAYOUT,
+            **kw)
         hip = col.hip
         build_s = time.time() - t0
         hip.set_stream(torch.cuda.current_stream().cuda_stream)
