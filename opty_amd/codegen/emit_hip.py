@@ -490,8 +490,13 @@ class _ModuleWriter(object):
         if self.line_mode():
             return K + 16
         if self.csr():
-            return max(b - a for e0, e1 in grp
-                       for a, b in self._chunks(e0, e1))
+            rs = self.p.row_start
+            wide = any(rs[j + 1] - rs[j] > CSR_MAX_ROW and K % 16 == 0
+                       for e0, e1 in grp for j in range(self.p.M)
+                       if e0 <= rs[j] < e1)
+            return max([K + 16 if wide else 0] +
+                       [b - a for e0, e1 in grp
+                        for a, b in self._chunks(e0, e1)])
         return min(K, width)
 
     def _group_body(self, grp, con_rows, slab_of):
@@ -553,31 +558,37 @@ class _ModuleWriter(object):
         body.end_scope()
         return body.lines
 
-    def _strip_lines(self, body, e0, e1, value, nv, R):
-        """Ring tile + line-aligned flush of one strip (see opty_device.h)."""
-        p = self.p
-        if e1 < p.P:
-            assert e1 + 15 <= p.P, 'last entry range must be >= 16 wide'
-        for c0, c1 in self._chunks(e0, e1 + 15):
+    def _strip_lines(self, body, e0, e1, value, nv, R, width=None,
+                     jrow='jrow', b0='b0'):
+        """Ring tile + line-aligned flush of one strip (see opty_device.h).
+        ``width`` doubles separate two nodes in the output (the block width P,
+        or one equation's row length in the row-sorted layout), ``jrow`` points
+        at the wave's first node there, ``b0`` is its line phase."""
+        P = self.p.P if width is None else width
+        K = self.o.chunk
+        if e1 < P:
+            assert e1 + 15 <= P, 'last entry range must be >= 16 wide'
+        for c0 in range(e0, e1 + 15, K):
+            c1 = min(c0 + K, e1 + 15)
             body.new_scope()
             for v in range(c0, c1):
                 body.begin_entry()
                 body.lines.append('ring[%d + lane] = %s;'
-                                  % ((v % R)*TS, value(v % p.P)))
+                                  % ((v % R)*TS, value(v % P)))
             body.lines.append('opty_wave_sync();')
             nlp = 1
             while 16*nlp < c1 - c0:
                 nlp *= 2
             body.lines.append(
-                'opty_flush_lines<%d, %d, %d>(ring, jrow, %d, b0, %d, %d,'
+                'opty_flush_lines<%d, %d, %d>(ring, %s, %d, %s, %d, %d,'
                 ' %d, %d, %d, %s, lane);' % (
-                    nlp, R, self.o.flush_unroll, p.P, c0 - 15,
+                    nlp, R, self.o.flush_unroll, jrow, P, b0, c0 - 15,
                     (c0 - 15) % R, e0, e1, c1, nv))
             if e0 == 0 and c0 == 0:
                 assert c1 >= 15
                 if self.o.ablate != 'compute_only':
-                    body.lines.append('opty_head_piece<%d>(ring, jrow, '
-                                      '%d, b0, lane);' % (R, p.P))
+                    body.lines.append('opty_head_piece<%d>(ring, %s, '
+                                      '%d, %s, lane);' % (R, jrow, P, b0))
             body.lines.append('opty_wave_sync();')
 
     def _strip_csr(self, body, e0, e1, value, nv):
@@ -585,25 +596,40 @@ class _ModuleWriter(object):
         are one contiguous span ``jac[S_j*ncn + i*L + pos]`` (``S_j`` entries
         precede row j in a block, ``ncn`` constraint nodes in this launch).
         Rows up to CSR_MAX_ROW entries are staged whole and written front to
-        back (opty_flush_flat); wider rows go out in chunk-wide pieces."""
+        back (opty_flush_flat); wider rows go through the ring tile with the
+        row as the "block" (line-aligned flush, as the node-major layout)."""
         p = self.p
-        for c0, c1 in self._chunks(e0, e1):
-            j = self._row_of(c0)
+        K = self.o.chunk
+        for j in range(p.M):
             S, L = p.row_start[j], p.row_start[j + 1] - p.row_start[j]
-            body.new_scope()
-            for e in range(c0, c1):
-                body.begin_entry()
-                body.lines.append('ring[%d + lane] = %s;'
-                                  % ((e - c0)*TS, value(e)))
-            body.lines.append('opty_wave_sync();')
+            if L == 0 or S < e0 or S >= e1:
+                continue
+            assert S + L <= e1, 'strips hold whole rows'
             dst = 'jac + %dLL*ncn + nloc*%dLL' % (S, L)
-            if c0 == S and c1 == S + L:
-                body.lines.append('opty_flush_flat<%d>(ring, %s, %s, lane);'
-                                  % (L, dst, nv))
-            else:
-                body.lines.append('opty_flush8<%d>(ring, %s + %d, %dLL, %s, '
-                                  'lane);' % (c1 - c0, dst, c0 - S, L, nv))
-            body.lines.append('opty_wave_sync();')
+            if L > CSR_MAX_ROW and K % 16 == 0:
+                body.end_scope()
+                body.lines.append('double *const jrow%d = %s;' % (j, dst))
+                body.lines.append('const int b0_%d = opty_line_phase(jrow%d);'
+                                  % (j, j))
+                body.scope_start = len(body.lines)
+                self._strip_lines(body, 0, L, lambda v: value(S + v), nv,
+                                  K + 16, L, 'jrow%d' % j, 'b0_%d' % j)
+                continue
+            for c0, c1 in self._chunks(S, S + L):
+                body.new_scope()
+                for e in range(c0, c1):
+                    body.begin_entry()
+                    body.lines.append('ring[%d + lane] = %s;'
+                                      % ((e - c0)*TS, value(e)))
+                body.lines.append('opty_wave_sync();')
+                if c0 == S and c1 == S + L:
+                    body.lines.append('opty_flush_flat<%d>(ring, %s, %s, '
+                                      'lane);' % (L, dst, nv))
+                else:
+                    body.lines.append('opty_flush8<%d>(ring, %s + %d, %dLL, '
+                                      '%s, lane);' % (c1 - c0, dst, c0 - S,
+                                                      L, nv))
+                body.lines.append('opty_wave_sync();')
 
     def _strip_simple(self, body, e0, e1, value, nv):
         """Per-chunk tile + flush for tiny blocks (P < 64)."""

@@ -416,31 +416,31 @@ def test_csr_layout_program_order(name, prune):
 def test_flat_flush_model(L):
     """Python model of ``opty_flush_flat`` (opty_amd/csrc/opty_device.h):
     every element of the span is written exactly once, from the right
-    (entry, node) of the tile, with 16-byte aligned pairs, for both
-    alignments of the span and ragged node counts."""
-    steps = (64*L + 1 + 127)//128
-    for phase in (0, 1):
+    (entry, node) of the tile, with 16-byte aligned pairs, for all sixteen
+    positions of the span start within a 128-byte line and ragged node
+    counts."""
+    steps = (64*L + 15 + 127)//128
+    for phase in range(16):
         for nvalid in (64, 1, 37):
             total = nvalid*L
             written = {}
             for it in range(steps):
                 for lane in range(64):
-                    f = 2*(it*64 + lane) - phase
-                    if f >= total:
-                        continue
+                    g = it*64 + lane
+                    f = 2*g - phase
                     f1 = f + 1
-                    if f >= 0 and f1 < total:
-                        assert (f + phase) % 2 == 0     # 16-byte aligned
-                        todo = (f, f1)
-                    elif f >= 0:
-                        todo = (f,)
-                    elif f1 < total:
-                        todo = (f1,)
-                    else:
-                        todo = ()
-                    for g in todo:
-                        assert g not in written
-                        written[g] = (g % L, g//L)       # tile[k][node]
+                    if not (f >= 0 and f1 < total):
+                        continue            # out-of-range buffer offset
+                    assert 16*g < (total + phase)*8   # inside the buffer
+                    for e in (f, f1):
+                        assert e not in written
+                        written[e] = (e % L, e//L)       # tile[k][node]
+            if phase & 1:                                # lane 0
+                assert 0 not in written
+                written[0] = (0, 0)
+            if (total + phase) & 1:                      # lane 1
+                assert total - 1 not in written
+                written[total - 1] = ((total - 1) % L, (total - 1)//L)
             assert sorted(written) == list(range(total))
             for g, (k, nd) in written.items():
                 assert g == nd*L + k and nd < nvalid

@@ -38,7 +38,10 @@ def main():
         workload = args.pop(0)
     specs = args or ['default']
     dev = torch.device('cuda:0')
-    kw = problems.build(workload)
+    factory, fkw = problems.CONFIGS[workload]
+    if os.environ.get('OPTY_TUNE_NODES'):
+        fkw = dict(fkw, num_nodes=int(os.environ['OPTY_TUNE_NODES']))
+    kw = factory(**fkw)
     iters = 30
     for spec in specs:
         opts = EmitOptions() if spec == 'default' else parse(spec)
