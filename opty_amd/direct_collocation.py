@@ -684,7 +684,9 @@ class Problem(object):
 
     The reference subclasses ``cyipopt.Problem``; ``cyipopt`` is imported
     lazily here so that the collocator, the callbacks and the bounds arrays
-    work without IPOPT.  ``solve`` needs ``cyipopt``.
+    work without IPOPT.  ``solve`` needs ``cyipopt``.  Extra keywords
+    ``device``, ``prune_zeros`` and ``jacobian_layout`` go to the collocator;
+    ``jacobianstructure()`` always matches what ``jacobian(free)`` returns.
     """
 
     INF = 10e19
@@ -695,7 +697,8 @@ class Problem(object):
                  instance_constraints=None, time_symbol=None, tmp_dir=None,
                  integration_method='backward euler', parallel=False,
                  bounds=None, show_compile_output=False, backend='hip',
-                 eom_bounds=None, device=0):
+                 eom_bounds=None, device=0, prune_zeros=False,
+                 jacobian_layout='coo'):
         if not sm.Matrix(equations_of_motion).has(sm.Derivative):
             raise ValueError('No time derivatives are present. The equations '
                              'of motion must be ordinary differential '
@@ -706,7 +709,8 @@ class Problem(object):
             node_time_interval, known_parameter_map, known_trajectory_map,
             instance_constraints, time_symbol, tmp_dir, integration_method,
             parallel, show_compile_output=show_compile_output,
-            backend=backend, device=device)
+            backend=backend, device=device, prune_zeros=prune_zeros,
+            jacobian_layout=jacobian_layout)
         self._bounds = bounds
         if eom_bounds is not None:
             bad = [k for k in eom_bounds

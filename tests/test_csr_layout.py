@@ -111,3 +111,27 @@ def test_csr_structure_needs_csr_layout():
     coo, _ = _pair('config1_vyasarayani')
     with pytest.raises(ValueError):
         coo.jacobian_csr_structure()
+
+
+def test_problem_facade_with_csr_layout():
+    """``Problem(..., jacobian_layout='csr', prune_zeros=True)``: the IPOPT
+    callbacks ``jacobianstructure`` / ``jacobian`` describe the same matrix as
+    the default layout."""
+    import opty_amd
+    kw = problems.pendulum_swing_up(num_nodes=130)
+    obj, grad = (lambda f: 0.0), (lambda f: f)
+    ref = opty_amd.Problem(obj, grad, **kw)
+    alt = opty_amd.Problem(obj, grad, jacobian_layout='csr',
+                           prune_zeros=True,
+                           **problems.pendulum_swing_up(num_nodes=130))
+    free = problems.make_free(ref.num_free, seed=9)
+    shape = (ref.num_constraints, ref.num_free)
+    A = sp.coo_matrix((ref.jacobian(free), ref.jacobianstructure()),
+                      shape=shape).tocsr()
+    B = sp.coo_matrix((alt.jacobian(free), alt.jacobianstructure()),
+                      shape=shape).tocsr()
+    assert len(alt.jacobian(free)) < len(ref.jacobian(free))
+    diff = abs(A - B)
+    assert (diff.max() if diff.nnz else 0.0) <= 1e-12*abs(A).max()
+    np.testing.assert_array_equal(alt.constraints(free),
+                                  ref.constraints(free))
