@@ -149,7 +149,8 @@ struct opty_hip_problem {
     double *d_free = nullptr, *d_con = nullptr, *d_jac = nullptr;  // staging
     long long *d_rows = nullptr, *d_cols = nullptr;                // staging
     double h = 0.0;
-    bool have_params = false, have_known = false, have_inst = false;
+    bool have_params = false, have_known = false, have_inst = false,
+         have_h = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     int64_t ncon_nodes() const { return d.N - 1; }
@@ -176,6 +177,9 @@ int check_ready(const opty_hip_problem *p) {
     if (p->d.num_inst > 0 && !p->have_inst)
         return fail("instance indices were never set "
                     "(opty_hip_set_instance_indices)");
+    if (p->d.s == 0 && !p->have_h)
+        return fail("the node time interval was never set "
+                    "(opty_hip_set_interval)");
     return 0;
 }
 
@@ -541,7 +545,11 @@ int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
 
 int opty_hip_set_interval(opty_hip_problem *p, double h) {
     if (!p) return fail("null handle");
+    if (!(h > 0.0) || h > 1.79e308)
+        return fail("the node time interval must be positive and finite, "
+                    "got %g", h);
     p->h = h;
+    p->have_h = true;
     p->uni_dirty = true;
     return 0;
 }

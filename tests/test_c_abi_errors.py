@@ -1,0 +1,84 @@
+"""GPU tests of the C ABI's error behaviour: every misuse returns a non-zero
+status with a message (raised as ``HipBackendError``) -- nothing is silently
+ignored, nothing falls back to a CPU path."""
+import numpy as np
+import pytest
+
+from opty_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(name='config1_vyasarayani', **kw):
+    """An un-configured handle for ``name`` (no parameters / interval set)."""
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    col = opty_amd.ConstraintCollocator(**kw, **problems.build(name))
+    source, meta = col.generate_source()
+    hsaco = hb.compile_module(source)
+    return col, hb.HipProblem(col._descriptor(meta), hsaco), hb
+
+
+def test_evaluation_before_configuration_fails():
+    col, hip, hb = _fresh('config2_pendulum_small')
+    free = problems.make_free(col.num_free)
+    con = np.empty(col.num_constraints)
+    with pytest.raises(hb.HipBackendError, match='parameter'):
+        hip.eval_con(free, con, hb.HOST)
+    hip.set_known_parameters([1.0, 1.0, 1.0, 9.81])
+    with pytest.raises(hb.HipBackendError):
+        hip.eval_con(free, con, hb.HOST)          # interval / instance map
+    hip.close()
+
+
+def test_wrong_counts_and_kinds_fail():
+    col, hip, hb = _fresh('config2_pendulum_small')
+    with pytest.raises(hb.HipBackendError, match='expected'):
+        hip.set_known_parameters([1.0, 2.0])
+    with pytest.raises(hb.HipBackendError):
+        hip.set_interval(0.0)
+    rows = np.empty(hip.nnz, dtype=np.int64)
+    cols = np.empty(hip.nnz, dtype=np.int64)
+    with pytest.raises(hb.HipBackendError, match='instance'):
+        hip.jacobian_indices(rows, cols, hb.HOST)
+    with pytest.raises(hb.HipBackendError, match='memory kind'):
+        col.hip.eval_con(problems.make_free(col.num_free),
+                         np.empty(col.num_constraints), 7)
+    hip.close()
+
+
+def test_bad_descriptor_and_code_object_fail():
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    col = opty_amd.ConstraintCollocator(
+        **problems.build('config1_vyasarayani'))
+    source, meta = col.generate_source()
+    hsaco = hb.compile_module(source)
+    good = col._descriptor(meta)
+    with pytest.raises(hb.HipBackendError, match='device'):
+        hb.HipProblem(dict(good, device=99), hsaco)
+    with pytest.raises(hb.HipBackendError, match='layout'):
+        hb.HipProblem(dict(good, layout=5), hsaco)
+    with pytest.raises(hb.HipBackendError):
+        hb.HipProblem(dict(good, N=1), hsaco)
+    with pytest.raises(hb.HipBackendError):
+        hb.HipProblem(good, '/nonexistent/module.hsaco')
+    # a code object of another problem lacks nothing by name but a pruned
+    # pattern that was never supplied is refused
+    pruned = opty_amd.ConstraintCollocator(
+        prune_zeros=True, **problems.build('config3_10link_small'))
+    src2, meta2 = pruned.generate_source()
+    hip = hb.HipProblem(pruned._descriptor(meta2), hb.compile_module(src2))
+    rows = np.empty(hip.nnz, dtype=np.int64)
+    with pytest.raises(hb.HipBackendError, match='pattern'):
+        hip.jacobian_indices(rows, rows.copy(), hb.HOST)
+    hip.close()
+
+
+def test_csr_layout_is_not_node_sharded():
+    col, hip, hb = _fresh('config3_10link_small', jacobian_layout='csr')
+    hip.set_block_pattern(col._build_program().pattern)
+    rows = np.empty(hip.nnz, dtype=np.int64)
+    with pytest.raises(hb.HipBackendError, match='shard'):
+        hip.jacobian_indices_shard(1000, 5, rows, rows.copy(), hb.HOST)
+    hip.close()
