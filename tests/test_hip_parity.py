@@ -396,3 +396,55 @@ def test_reference_unit_test_fixtures(name):
         np.testing.assert_array_equal(cols, case['cols'])
     np.testing.assert_allclose(coo_to_dense(jac, rows, cols), case['dense'],
                                rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('name,N,layout', [
+    ('config3_10link_small', 100000, 'coo'),
+    ('config3_10link_small', 100000, 'csr'),
+    ('config5_standin_24link_small', 50000, 'coo'),
+    ('pend3_link_midpoint_small', 20011, 'coo')])
+def test_golden_window_embedded_at_full_size(name, N, layout):
+    """Size-independent property at BASELINE.json's full sizes: a constraint
+    node sees only its own two time nodes and the shared scalars, so the
+    reference's small fixture, pasted into a window of a full-size ``free``
+    vector, must reproduce the reference's values in exactly that window --
+    at any offset, across 64-node block boundaries and at both ends."""
+    import opty_amd
+    meta, z = gu.load(name)
+    n_small, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    factory, fkw = problems.CONFIGS[name]
+    col = opty_amd.ConstraintCollocator(
+        jacobian_layout=layout, **factory(**dict(fkw, num_nodes=N)))
+    nrows = meta['n'] + meta['q']
+    small = z['free']
+    tail = small[nrows*n_small:]
+    gcon = z['con'][:M*(n_small - 1)].reshape(M, n_small - 1)
+    gjac = z['jac'][:P*(n_small - 1)].reshape(n_small - 1, P)
+    if layout == 'csr':
+        prog = col._build_program()
+        sel = [j*C + k for j, k in prog.pattern]
+        rs = prog.row_start
+    con_f = col.generate_constraint_function()
+    jac_f = col.generate_jacobian_function()
+    for off in (0, 63, 12345 % (N - n_small), N - n_small):
+        free = problems.make_free(col.num_free, seed=off)
+        for r in range(nrows):
+            free[r*N + off:r*N + off + n_small] = \
+                small[r*n_small:(r + 1)*n_small]
+        free[nrows*N:] = tail
+        con = con_f(free)[:M*(N - 1)].reshape(M, N - 1)
+        jac = jac_f(free)
+        gu.assert_close(con[:, off:off + n_small - 1], gcon, RTOL,
+                        what='%s con window @%d' % (name, off))
+        if layout == 'coo':
+            win = jac[:P*(N - 1)].reshape(N - 1, P)[off:off + n_small - 1]
+            gu.assert_close(win, gjac, RTOL,
+                            what='%s jac window @%d' % (name, off))
+        else:
+            for j in range(M):
+                L = rs[j + 1] - rs[j]
+                blk = jac[rs[j]*(N - 1):rs[j + 1]*(N - 1)].reshape(N - 1, L)
+                gu.assert_close(blk[off:off + n_small - 1],
+                                gjac[:, sel[rs[j]:rs[j + 1]]], RTOL,
+                                what='%s csr row %d @%d' % (name, j, off))
