@@ -95,6 +95,11 @@ def main():
                     help='strong scaling: --nodes is the GLOBAL node count, '
                          'sharded over the ranks (default: weak scaling, '
                          '--nodes per rank)')
+    ap.add_argument('--to-host', action='store_true',
+                    help='every rank also copies its con/jac shard into its '
+                         'own page-locked host buffer each step (the '
+                         'PCIe-inclusive rate a host-side IPOPT sees; never '
+                         'the headline value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -150,6 +155,11 @@ def main():
         gathered = (torch.empty(world*ncon, dtype=torch.float64, device=dev),
                     torch.empty(world*nnz, dtype=torch.float64, device=dev))
 
+    hosted = None
+    if args.to_host:
+        hosted = (torch.empty(ncon, dtype=torch.float64).pin_memory(),
+                  torch.empty(nnz, dtype=torch.float64).pin_memory())
+
     def step(k):
         f = frees[k % len(frees)]
         if args.serial:
@@ -160,6 +170,9 @@ def main():
         if gathered is not None:
             dist.all_gather_into_tensor(gathered[0], con)
             dist.all_gather_into_tensor(gathered[1], jac)
+        if hosted is not None:
+            hosted[0].copy_(con, non_blocking=True)
+            hosted[1].copy_(jac, non_blocking=True)
 
     def barrier():
         if world > 1:
@@ -235,7 +248,10 @@ def main():
                 'sharding': 'nodes sharded one contiguous range per GPU, '
                             'outputs left distributed' +
                             (', + RCCL all-gather of con and jac'
-                             if gathered is not None else ''),
+                             if gathered is not None else '') +
+                            (', + device-to-host copy of every shard into '
+                             'page-locked memory' if hosted is not None
+                             else ''),
                 'oversubscribed': bool(oversub),
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
