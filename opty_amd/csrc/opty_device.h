@@ -45,6 +45,11 @@
 //   long long con_stride      distance between two equations in `con`
 //   long long node_begin/end  constraint-node range this launch evaluates
 
+// Cache-policy bits of the flush stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+#ifndef OPTY_STORE_AUX
+#define OPTY_STORE_AUX 0
+#endif
+
 #define OPTY_WAVE 64
 // LDS row stride (in doubles) of both the input slab and the output tile.
 // 65 = 1 (mod 16) makes the transposing reads of the flush hit 32 distinct
@@ -176,11 +181,6 @@ __device__ __forceinline__ int opty_line_phase(const double *p) {
 }
 
 typedef unsigned int opty_u32x4 __attribute__((ext_vector_type(4)));
-
-// Cache-policy bits of the flush stores (gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
-#ifndef OPTY_STORE_AUX
-#define OPTY_STORE_AUX 0
-#endif
 
 // Buffer resource over the wave's output block [jrow, jrow + bytes): raw
 // (stride 0) addressing with hardware range checking -- a store whose byte

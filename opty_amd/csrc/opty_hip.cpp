@@ -36,8 +36,10 @@ int fail(const char *fmt, ...) {
 #define HIP_TRY(expr)                                                         \
     do {                                                                      \
         hipError_t e_ = (expr);                                               \
-        if (e_ != hipSuccess)                                                 \
+        if (e_ != hipSuccess) {                                               \
+            (void)hipGetLastError(); /* the runtime's error state is sticky */\
             return fail("%s failed: %s", #expr, hipGetErrorString(e_));       \
+        }                                                                     \
     } while (0)
 
 // The packed kernarg buffer; must match the parameter list every generated
@@ -324,6 +326,7 @@ int opty_hip_objective_create(const opty_hip_objective_desc *desc,
     hipError_t e = hipModuleLoad(&o->module, code_object_path);
     if (e != hipSuccess) {
         delete o;
+        (void)hipGetLastError();
         return fail("hipModuleLoad(%s) failed: %s", code_object_path,
                     hipGetErrorString(e));
     }
@@ -459,6 +462,7 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
     hipError_t e = hipModuleLoad(&p->module, code_object_path);
     if (e != hipSuccess) {
         delete p;
+        (void)hipGetLastError();
         return fail("hipModuleLoad(%s) failed: %s", code_object_path,
                     hipGetErrorString(e));
     }
@@ -701,6 +705,7 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     // enough entries per block to keep 256 lanes busy
     int npb = P >= 1024 ? 1 : (1024 + P - 1)/P;
     const unsigned grid = (unsigned)((d.count + npb - 1)/npb);
+    (void)hipGetLastError();    // drop whatever an earlier failed call left
     hipLaunchKernelGGL(opty_indices_kernel, dim3(grid), dim3(256), 0,
                        p->stream, d, dr, dc, npb);
     HIP_TRY(hipGetLastError());

@@ -444,3 +444,21 @@ def test_flat_flush_model(L):
             assert sorted(written) == list(range(total))
             for g, (k, nd) in written.items():
                 assert g == nd*L + k and nd < nvalid
+
+
+def test_objective_modules_build_for_gfx950(tmp_path):
+    """The objective / gradient kernels of every reference case cross-compile
+    (they include the same device header as the collocation kernels)."""
+    import objective_cases
+    from opty_amd import hip_backend as hb
+    from opty_amd.objective import build_objective_program, _emit
+    t, cases = objective_cases.cases()
+    seen = set()
+    for case in cases:
+        states, inputs, unknowns = case['args']
+        dag, roots, n, q, r = build_objective_program(
+            case['expr'], states, inputs, unknowns, case['method'], t)
+        source = _emit(dag, n + q, r, 11, case['method'], roots)
+        if source not in seen:
+            seen.add(source)
+            assert os.path.getsize(hb.compile_module(source, str(tmp_path)))

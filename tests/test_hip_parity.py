@@ -448,3 +448,23 @@ def test_golden_window_embedded_at_full_size(name, N, layout):
                 gu.assert_close(blk[off:off + n_small - 1],
                                 gjac[:, sel[rs[j]:rs[j + 1]]], RTOL,
                                 what='%s csr row %d @%d' % (name, j, off))
+
+
+@pytest.mark.parametrize('name', ['config3_10link_small',
+                                  'elementary_mid_small'])
+def test_optimisation_levels_agree(name, monkeypatch):
+    """The same generated module built by hipcc at -O1 and at the default
+    level goes through different compiler pipelines and must agree to
+    rounding (a -O3 build of a 24-link kernel once did not: DESIGN.md 4.6)."""
+    import opty_amd
+    out = {}
+    for lvl in (None, '-O1'):
+        if lvl:
+            monkeypatch.setenv('OPTY_HIPCC_OPT', lvl)
+        col = opty_amd.ConstraintCollocator(**problems.build(name))
+        free = problems.make_free(col.num_free, seed=11,
+                                  variable_duration=col._variable_duration)
+        out[lvl] = (col.generate_constraint_function()(free).copy(),
+                    col.generate_jacobian_function()(free).copy())
+    for a, b in zip(out[None], out['-O1']):
+        assert np.abs(a - b).max() <= 1e-12*np.abs(a).max()
