@@ -339,12 +339,20 @@ int opty_hip_objective_create(const opty_hip_objective_desc *desc,
         return fail("opty_objgrad/opty_objfin missing from %s",
                     code_object_path);
     }
-    HIP_TRY(hipStreamCreateWithFlags(&o->own_stream, hipStreamNonBlocking));
-    o->stream = o->own_stream;
-    o->nblk = (desc->N + 63)/64;
-    HIP_TRY(hipMalloc((void **)&o->d_partial,
-                      (size_t)o->nblk*(1 + desc->r)*sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&o->d_value, sizeof(double)));
+    auto allocate = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&o->own_stream,
+                                         hipStreamNonBlocking));
+        o->stream = o->own_stream;
+        o->nblk = (desc->N + 63)/64;
+        HIP_TRY(hipMalloc((void **)&o->d_partial,
+                          (size_t)o->nblk*(1 + desc->r)*sizeof(double)));
+        HIP_TRY(hipMalloc((void **)&o->d_value, sizeof(double)));
+        return 0;
+    };
+    if (int rc = allocate()) {
+        (void)opty_hip_objective_destroy(o);
+        return rc;
+    }
     *out = o;
     return 0;
 }
@@ -483,19 +491,27 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
                         code_object_path, hipGetErrorString(e));
         }
     }
-    HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
-    p->stream = p->own_stream;
-    HIP_TRY(hipEventCreate(&p->ev0));
-    HIP_TRY(hipEventCreate(&p->ev1));
-    if (desc->p_known > 0)
-        HIP_TRY(hipMalloc((void **)&p->d_params,
-                          desc->p_known*sizeof(double)));
-    if (desc->num_uniform > 0)
-        HIP_TRY(hipMalloc((void **)&p->d_uni,
-                          desc->num_uniform*sizeof(double)));
-    if (desc->m_known > 0)
-        HIP_TRY(hipMalloc((void **)&p->d_known,
-                          (size_t)desc->m_known*desc->N*sizeof(double)));
+    auto allocate = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&p->own_stream,
+                                         hipStreamNonBlocking));
+        p->stream = p->own_stream;
+        HIP_TRY(hipEventCreate(&p->ev0));
+        HIP_TRY(hipEventCreate(&p->ev1));
+        if (desc->p_known > 0)
+            HIP_TRY(hipMalloc((void **)&p->d_params,
+                              desc->p_known*sizeof(double)));
+        if (desc->num_uniform > 0)
+            HIP_TRY(hipMalloc((void **)&p->d_uni,
+                              desc->num_uniform*sizeof(double)));
+        if (desc->m_known > 0)
+            HIP_TRY(hipMalloc((void **)&p->d_known,
+                              (size_t)desc->m_known*desc->N*sizeof(double)));
+        return 0;
+    };
+    if (int rc = allocate()) {
+        (void)opty_hip_destroy(p);      // releases whatever was acquired
+        return rc;
+    }
     *out = p;
     return 0;
 }

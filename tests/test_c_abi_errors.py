@@ -82,3 +82,35 @@ def test_csr_layout_is_not_node_sharded():
     with pytest.raises(hb.HipBackendError, match='shard'):
         hip.jacobian_indices_shard(1000, 5, rows, rows.copy(), hb.HOST)
     hip.close()
+
+
+def test_handles_release_their_device_memory():
+    """Creating, using and destroying handles in a loop returns the device
+    memory (staging buffers, tables, module) every time."""
+    import torch
+    import opty_amd
+    kw = problems.build('config3_10link_small')
+    col = opty_amd.ConstraintCollocator(**kw)
+    source, meta = col.generate_source()
+    from opty_amd import hip_backend as hb
+    hsaco = hb.compile_module(source)
+    free = problems.make_free(col.num_free)
+    con = np.empty(col.num_constraints)
+
+    def cycle():
+        hip = hb.HipProblem(col._descriptor(meta), hsaco)
+        hip.set_known_parameters([float(col.known_parameter_map[p])
+                                  for p in col.known_parameters])
+        hip.set_interval(col.node_time_interval)
+        jac = np.empty(hip.nnz)
+        hip.eval_con_jac(free, con, jac, hb.HOST)
+        hip.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    after = torch.cuda.mem_get_info()[0]
+    assert before - after < 8 << 20, (before, after)
