@@ -244,6 +244,31 @@ def elementary_functions(num_nodes=45, method='backward euler',
                 integration_method=method)
 
 
+def delay_equation(num_nodes=51, method='backward euler'):
+    """Six chained delay segments with six algebraic path constraints
+    (M = 12 equations for n = 6 states), six unknown inputs and twelve
+    instance constraints that couple *two* function atoms each, inputs
+    included -- the system of the reference's gallery example
+    ``examples-gallery/beginner/plot_betts_10_50.py:52-110``."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    x = me.dynamicsymbols('x1:7')
+    u = me.dynamicsymbols('u1:7')
+    prev = [sm.Float(0.0), x[0]*0.0] + [x[k]*u[k - 1] for k in range(1, 5)]
+    # -x1' + x0*u_{-1}, -x2' + x1*u0 (u_{-1} = u0 = 0), then -x_k' + x_{k-1}*u_{k-2}
+    eom = sm.Matrix([-x[k].diff(t) + prev[k] for k in range(6)] +
+                    [u[k] + x[k] for k in range(6)])
+    t0, tf = 0.0, 1.0
+    inst = tuple([x[0].func(t0) - 1.0] +
+                 [x[k].func(t0) - x[k - 1].func(tf) for k in range(1, 6)] +
+                 [u[k].func(t0) + x[k].func(t0) - 0.5 for k in range(6)])
+    return dict(equations_of_motion=eom, state_symbols=tuple(x),
+                num_collocation_nodes=num_nodes,
+                node_time_interval=(tf - t0)/(num_nodes - 1),
+                instance_constraints=inst, time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -273,6 +298,9 @@ CONFIGS = {
     'implicit_traj_mid_small': (implicit_known_trajectory,
                                 {'num_nodes': 33, 'method': 'midpoint',
                                  'variable_duration': False}),
+    'delay_be_small': (delay_equation, {}),
+    'delay_mid_small': (delay_equation, {'num_nodes': 66,
+                                         'method': 'midpoint'}),
     'elementary_be_small': (elementary_functions, {}),
     'elementary_mid_small': (elementary_functions,
                              {'num_nodes': 70, 'method': 'midpoint',

@@ -46,7 +46,7 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'chaplygin_be_small', 'chaplygin_mid_small', 'one_eom_be_small',
          'one_eom_mid_small', 'implicit_traj_be_small',
          'implicit_traj_mid_small', 'elementary_be_small',
-         'elementary_mid_small']
+         'elementary_mid_small', 'delay_be_small', 'delay_mid_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
 
 
@@ -72,6 +72,13 @@ def run(name):
     cv = con(free).copy()
     jv = jac(free).copy()
     o = col.num_instance_constraints
+    # The reference orders the partials of an instance constraint with two or
+    # more function atoms by iterating a set; fixtures
+    # store that tail in canonical order: by row, then column.
+    base = len(rows) - sum(len(c.atoms(sm.Function))
+                           for c in (col.instance_constraints or ()))
+    order = base + np.lexsort((cols[base:], rows[base:]))
+    rows[base:], cols[base:], jv[base:] = rows[order], cols[order], jv[order]
     qn = col.num_unknown_input_trajectories
     C = (2*col.num_states + (1 if col.integration_method ==
                              'backward euler' else 2)*qn +
