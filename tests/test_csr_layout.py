@@ -135,3 +135,21 @@ def test_problem_facade_with_csr_layout():
     assert (diff.max() if diff.nnz else 0.0) <= 1e-12*abs(A).max()
     np.testing.assert_array_equal(alt.constraints(free),
                                   ref.constraints(free))
+
+
+def test_end_to_end_swing_up_with_csr_jacobian():
+    """``examples/swing_up_scipy.py``: device objective + gradient, device
+    constraints and a CSR Jacobian drive SciPy's SLSQP to a feasible
+    minimum-effort swing-up."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(__file__), '..', 'examples',
+                        'swing_up_scipy.py')
+    spec = importlib.util.spec_from_file_location('swing_up_scipy', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    free, res, violation = mod.main(verbose=False)
+    N = 41
+    assert res.success and violation < 1e-8
+    assert abs(free[N - 1] - np.pi) < 1e-8 and abs(free[0]) < 1e-8
+    assert abs(res.fun - 59.65) < 0.5
