@@ -42,6 +42,9 @@ LINE_MODE_MIN_P = 64
 #: csr layout: rows up to this many entries are staged whole and written
 #: as one contiguous span per wave (tile = 65*8 bytes per entry)
 CSR_MAX_ROW = 64
+#: workgroups the runtime launches opty_uni with (OPTY_UNI_WORKGROUPS in
+#: opty_hip.cpp)
+UNI_WORKGROUPS = 16
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -789,15 +792,27 @@ class _ModuleWriter(object):
                 return self._scalar_source(i)
             return None
 
-        body = _Body(d, needed, leaf)
-        for i, s in slots:
-            ref = body.emit(i)
-            body.lines.append('uni_w[%d] = %s;' % (s, ref))
-        body.end_scope()
+        # The table is filled by up to UNI_WORKGROUPS single-lane workgroups
+        # (problems whose table depends on `free` -- variable duration,
+        # unknown parameters -- pay for this kernel in every evaluation); each
+        # takes a contiguous share of the slots and recomputes what it shares
+        # with the others.
+        nparts = max(1, min(UNI_WORKGROUPS, len(slots)//48))
         src = ['extern "C" __global__ void __launch_bounds__(64)',
                'opty_uni(%s)' % KERNEL_PARAMS, '{',
-               '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
-        src += ['    ' + ln for ln in body.lines] + ['}']
+               '    if (threadIdx.x != 0) return;',
+               '    switch (blockIdx.x) {']
+        for b in range(nparts):
+            part = slots[b*len(slots)//nparts:(b + 1)*len(slots)//nparts]
+            body = _Body(d, set(d.reachable([i for i, _ in part])), leaf)
+            for i, s in part:
+                ref = body.emit(i)
+                body.lines.append('uni_w[%d] = %s;' % (s, ref))
+            body.end_scope()
+            src.append('    case %d: {' % b)
+            src += ['        ' + ln for ln in body.lines]
+            src.append('    } break;')
+        src += ['    default: break;', '    }', '}']
         dynamic = any(d.op[i] == ir.INPUT and
                       self._scalar_source(i).startswith('free_')
                       for i in needed)

@@ -42,6 +42,10 @@ int fail(const char *fmt, ...) {
         }                                                                     \
     } while (0)
 
+// opty_uni fills the node-invariant table with up to this many single-lane
+// workgroups (the generated kernel switches on blockIdx.x; surplus ones exit).
+#define OPTY_UNI_WORKGROUPS 16
+
 // The packed kernarg buffer; must match the parameter list every generated
 // kernel has (KERNEL_PARAMS in opty_amd/codegen/emit_hip.py).
 struct KernelArgs {
@@ -185,8 +189,9 @@ int check_ready(const opty_hip_problem *p) {
     return 0;
 }
 
-// wgs_per_block: workgroups per 64-node block (0: a single one-wave launch);
-// threads: workgroup size.
+// wgs_per_block: workgroups per 64-node block (0: a single one-wave launch,
+// < 0: that many workgroups regardless of the node count); threads: workgroup
+// size.
 int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
            int threads, const double *free_, double *con, double *jac) {
     KernelArgs a;
@@ -208,7 +213,9 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
                       HIP_LAUNCH_PARAM_END};
     unsigned grid = 1;
-    if (wgs_per_block > 0) {
+    if (wgs_per_block < 0) {
+        grid = (unsigned)(-wgs_per_block);      // plain grid, no node blocks
+    } else if (wgs_per_block > 0) {
         // node blocks padded to a multiple of the 8 XCDs (see the kernels'
         // prologue: block -> XCD placement); surplus workgroups exit at once
         const long long nblk = ((p->ncon_nodes() + 63)/64 + 7)/8*8;
@@ -227,7 +234,8 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
     // Node-invariant sub-expressions: recomputed only when their inputs can
     // have changed (always, if they read unknown parameters / h from `free`).
     if (p->d.num_uniform > 0 && (p->uni_dirty || p->d.uniform_dynamic)) {
-        if (int rc = launch(p, p->k_uni, 0, 64, free_, nullptr, nullptr)) return rc;
+        if (int rc = launch(p, p->k_uni, -OPTY_UNI_WORKGROUPS, 64, free_, nullptr,
+                                nullptr)) return rc;
         p->uni_dirty = false;
     }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
@@ -772,7 +780,8 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
     if (int rc = check_ready(p)) return rc;
     if (p->d.num_uniform > 0 && p->uni_dirty && !p->d.uniform_dynamic) {
         // keep the one-off table fill out of the timed region
-        if (int rc = launch(p, p->k_uni, 0, 64, free_, nullptr, nullptr)) return rc;
+        if (int rc = launch(p, p->k_uni, -OPTY_UNI_WORKGROUPS, 64, free_, nullptr,
+                                nullptr)) return rc;
         p->uni_dirty = false;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
