@@ -101,16 +101,24 @@ int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream);
 int opty_hip_synchronize(opty_hip_problem *p);
 
 /* Values of the known parameters in ConstraintCollocator.known_parameters
- * order (replaces the scalar by-value arguments c0.. of eval_matrix). */
+ * order.  Replaces the scalar by-value arguments c0.. of eval_matrix
+ * (opty/utils.py:489-490) that _multi_arg_con_func passes on every call
+ * (opty/direct_collocation.py:2436-2437). */
 int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
                                   int32_t count);
-/* Node time interval when it is not a free variable. */
+/* Node time interval when it is not a free variable; must be set before the
+ * first evaluation (the reference passes `interval_value` per call,
+ * opty/direct_collocation.py:2382-2385, :2437). */
 int opty_hip_set_interval(opty_hip_problem *p, double h);
-/* (m_known x N) row-major host array, known_input_trajectories order. */
+/* (m_known x N) row-major array, known_input_trajectories order: the known
+ * rows _merge_fixed_free interleaves into the specifieds
+ * (opty/direct_collocation.py:2891-2926). */
 int opty_hip_set_known_trajectories(opty_hip_problem *p, const double *values,
                                     int32_t mem);
-/* Instance constraints: free-vector index of every atom, and the COO
- * rows/cols of the instance part of the Jacobian (host arrays). */
+/* Instance constraints: free-vector index of every atom
+ * (_find_closest_free_index, opty/direct_collocation.py:2169-2217) and the COO
+ * rows/cols of the instance part of the Jacobian
+ * (_instance_constraints_jacobian_indices, :2233-2251); host arrays. */
 int opty_hip_set_instance_indices(opty_hip_problem *p,
                                   const int64_t *atom_free_index,
                                   const int64_t *rows, const int64_t *cols);
@@ -124,16 +132,24 @@ int64_t opty_hip_num_free(const opty_hip_problem *p);
 int64_t opty_hip_num_constraints(const opty_hip_problem *p);
 int64_t opty_hip_nnz(const opty_hip_problem *p);
 
-/* constraints(free): writes num_constraints doubles. */
+/* constraints(free): writes num_constraints doubles.  Replaces the closure
+ * built by _wrap_constraint_funcs(..., 'con') (opty/direct_collocation.py:
+ * 2952-2993) including _multi_arg_con_func (:2382-2446) and the compiled
+ * eval_matrix_loop (opty/utils.py:500-529). */
 int opty_hip_eval_con(opty_hip_problem *p, const double *free, double *con,
                       int32_t mem);
-/* jacobian(free): writes nnz doubles. */
+/* jacobian(free): writes nnz doubles.  Replaces the 'jac' closure of
+ * _wrap_constraint_funcs and _multi_arg_con_jac_func
+ * (opty/direct_collocation.py:2816-2887). */
 int opty_hip_eval_jac(opty_hip_problem *p, const double *free, double *jac,
                       int32_t mem);
-/* both from one kernel launch (shared sub-expressions). */
+/* both of the above for one `free` from one kernel launch (no reference
+ * counterpart: IPOPT asks for them separately, :498-525, :552-562). */
 int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
                           double *jac, int32_t mem);
-/* jacobian_indices(): writes nnz int64 rows and cols. */
+/* jacobian_indices(): writes nnz int64 rows and cols -- the closed form of
+ * ConstraintCollocator.jacobian_indices (opty/direct_collocation.py:2450-2690,
+ * formulas :2644-2675). */
 int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
                               int64_t *cols, int32_t mem);
 
