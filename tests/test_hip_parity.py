@@ -402,6 +402,7 @@ def test_reference_unit_test_fixtures(name):
     ('config3_10link_small', 100000, 'coo'),
     ('config3_10link_small', 100000, 'csr'),
     ('config5_standin_24link_small', 50000, 'coo'),
+    ('config5_standin_24link_small', 50000, 'csr'),
     ('pend3_link_midpoint_small', 20011, 'coo')])
 def test_golden_window_embedded_at_full_size(name, N, layout):
     """Size-independent property at BASELINE.json's full sizes: a constraint
@@ -468,3 +469,44 @@ def test_optimisation_levels_agree(name, monkeypatch):
                     col.generate_jacobian_function()(free).copy())
     for a, b in zip(out[None], out['-O1']):
         assert np.abs(a - b).max() <= 1e-12*np.abs(a).max()
+
+
+def test_million_node_problem_device_windows():
+    """Ten times BASELINE's node count (N = 1 000 001: 7.9 GB of Jacobian,
+    64-bit offsets everywhere): the reference's 41-node fixture embedded at
+    the start, deep inside and at the very end, checked on device slices."""
+    import torch
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    meta, z = gu.load('config3_10link_small')
+    n_small, M, C = meta['N'], meta['M'], meta['C']
+    P, nrows = M*C, meta['n'] + meta['q']
+    N = 1000001
+    factory, fkw = problems.CONFIGS['config3_10link_small']
+    col = opty_amd.ConstraintCollocator(**factory(**dict(fkw, num_nodes=N)))
+    hip = col.hip
+    dev = torch.device('cuda', 0)
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    free = problems.make_free(col.num_free, seed=77)
+    offsets = (0, 987654, N - n_small)
+    for off in offsets:
+        for r in range(nrows):
+            free[r*N + off:r*N + off + n_small] = \
+                z['free'][r*n_small:(r + 1)*n_small]
+    f = torch.from_numpy(free).to(dev)
+    con = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
+    jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+    hip.eval_con_jac(f, con, jac, hb.DEVICE)
+    torch.cuda.synchronize()
+    gcon = z['con'].reshape(M, n_small - 1)
+    gjac = z['jac'].reshape(n_small - 1, P)
+    cv = con.view(M, N - 1)
+    jv = jac.view(N - 1, P)
+    for off in offsets:
+        gu.assert_close(cv[:, off:off + n_small - 1].cpu().numpy(), gcon,
+                        RTOL, what='con window @%d' % off)
+        gu.assert_close(jv[off:off + n_small - 1].cpu().numpy(), gjac, RTOL,
+                        what='jac window @%d' % off)
+    # the nodes in between are finite and not left unwritten
+    probe = jv[::9973]
+    assert torch.isfinite(probe).all()
