@@ -269,6 +269,25 @@ def delay_equation(num_nodes=51, method='backward euler'):
                 integration_method=method)
 
 
+def odd_block_chain(num_nodes=75, method='backward euler'):
+    """Seven coupled first-order equations with one unknown parameter:
+    M = n = 7, C = 15, so the per-node block has an ODD number of entries
+    (P = 105 >= 64): node rows alternate between 16-byte aligned and
+    misaligned, the case the line-aligned flush's straddling pieces exist
+    for.  Not from the reference's examples."""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    p, c = sm.symbols('p, c', real=True)
+    x = me.dynamicsymbols('x1:8', real=True)
+    eom = sm.Matrix([x[k].diff() + p*x[k] - c*x[k - 1]*sm.sin(x[k])
+                     - sm.cos(x[(k + 2) % 7])*x[(k + 3) % 7]
+                     for k in range(7)])
+    return dict(equations_of_motion=eom, state_symbols=tuple(x),
+                num_collocation_nodes=num_nodes, node_time_interval=0.04,
+                known_parameter_map={c: 0.7}, time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -298,6 +317,9 @@ CONFIGS = {
     'implicit_traj_mid_small': (implicit_known_trajectory,
                                 {'num_nodes': 33, 'method': 'midpoint',
                                  'variable_duration': False}),
+    'odd_block_be_small': (odd_block_chain, {}),
+    'odd_block_mid_small': (odd_block_chain, {'num_nodes': 130,
+                                              'method': 'midpoint'}),
     'delay_be_small': (delay_equation, {}),
     'delay_mid_small': (delay_equation, {'num_nodes': 66,
                                          'method': 'midpoint'}),

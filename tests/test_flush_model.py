@@ -112,7 +112,8 @@ def parse_groups(source, kernel='opty_jac'):
     (16, None, 1), (32, 1, 1), (32, 3, 1), (64, 4, 0), (16, 7, 1),
     (32, None, 0), (32, 6, 0)])
 @pytest.mark.parametrize('name', ['config3_10link_small',
-                                  'pend3_link_midpoint_small'])
+                                  'pend3_link_midpoint_small',
+                                  'odd_block_be_small'])
 def test_every_element_written_once(name, chunk, groups, interleave):
     col = ConstraintCollocator(**problems.build(name))
     prog = col._build_program()
