@@ -269,12 +269,14 @@ def delay_equation(num_nodes=51, method='backward euler'):
                 integration_method=method)
 
 
-def odd_block_chain(num_nodes=75, method='backward euler'):
+def odd_block_chain(num_nodes=75, method='backward euler',
+                    unknown_parameter=True):
     """Seven coupled first-order equations with one unknown parameter:
     M = n = 7, C = 15, so the per-node block has an ODD number of entries
     (P = 105 >= 64): node rows alternate between 16-byte aligned and
     misaligned, the case the line-aligned flush's straddling pieces exist
-    for.  Not from the reference's examples."""
+    for.  With ``unknown_parameter=False`` nothing but the states is free
+    (q = r = s = 0).  Not from the reference's examples."""
     me.dynamicsymbols._t = sm.Symbol('t')
     t = me.dynamicsymbols._t
     p, c = sm.symbols('p, c', real=True)
@@ -284,8 +286,9 @@ def odd_block_chain(num_nodes=75, method='backward euler'):
                      for k in range(7)])
     return dict(equations_of_motion=eom, state_symbols=tuple(x),
                 num_collocation_nodes=num_nodes, node_time_interval=0.04,
-                known_parameter_map={c: 0.7}, time_symbol=t,
-                integration_method=method)
+                known_parameter_map={c: 0.7} if unknown_parameter
+                else {c: 0.7, p: 0.3},
+                time_symbol=t, integration_method=method)
 
 
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
@@ -317,6 +320,9 @@ CONFIGS = {
     'implicit_traj_mid_small': (implicit_known_trajectory,
                                 {'num_nodes': 33, 'method': 'midpoint',
                                  'variable_duration': False}),
+    'states_only_mid_small': (odd_block_chain,
+                              {'num_nodes': 66, 'method': 'midpoint',
+                               'unknown_parameter': False}),
     'odd_block_be_small': (odd_block_chain, {}),
     'odd_block_mid_small': (odd_block_chain, {'num_nodes': 130,
                                               'method': 'midpoint'}),

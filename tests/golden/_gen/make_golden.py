@@ -47,7 +47,8 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'one_eom_mid_small', 'implicit_traj_be_small',
          'implicit_traj_mid_small', 'elementary_be_small',
          'elementary_mid_small', 'delay_be_small', 'delay_mid_small',
-         'odd_block_be_small', 'odd_block_mid_small']
+         'odd_block_be_small', 'odd_block_mid_small',
+         'states_only_mid_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
 
 
