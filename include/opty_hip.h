@@ -79,10 +79,12 @@ typedef struct opty_hip_desc {
     int32_t jac_wgs_per_block; /* workgroups per 64-node block (opty_jac)    */
     int32_t jac_waves_per_wg;  /* 64-lane waves per such workgroup           */
     int32_t fused_wgs_per_block; /* workgroups per block of opty_conjac      */
-    int32_t con_wgs_per_block; /* one-wave workgroups per block of opty_con  */
+    int32_t con_wgs_per_block; /* workgroups per block of opty_con           */
     int32_t num_uniform;  /* entries of the node-invariant table (opty_uni)  */
     int32_t uniform_dynamic; /* 1 if that table depends on `free` (r+s > 0)  */
     int32_t device;       /* HIP device ordinal                              */
+    int32_t fused_waves_per_wg; /* waves per workgroup of opty_conjac         */
+    int32_t con_waves_per_wg;   /* waves per workgroup of opty_con            */
     int32_t layout;       /* OPTY_HIP_LAYOUT_COO: the reference's node-major
                              order jac[i*P + e]; OPTY_HIP_LAYOUT_CSR: sorted by
                              row then column, jac[S_j*(N-1) + i*L_j + pos]

@@ -239,13 +239,15 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
         p->uni_dirty = false;
     }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block, 64, free_, con,
-                            nullptr)) return rc;
+        if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block,
+                            64*p->d.con_waves_per_wg, free_, con, nullptr))
+            return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac)) return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
-        if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block, T, free_, con,
-                            jac)) return rc;
+        if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
+                            64*p->d.fused_waves_per_wg, free_, con, jac))
+            return rc;
     if (p->d.num_inst > 0) {
         double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr : con;
         double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr : jac;
@@ -463,7 +465,9 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
         return fail("bad layout %d", desc->layout);
     if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
         desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1 ||
-        desc->con_wgs_per_block < 1)
+        desc->con_wgs_per_block < 1 || desc->fused_waves_per_wg < 1 ||
+        desc->fused_waves_per_wg > 16 || desc->con_waves_per_wg < 1 ||
+        desc->con_waves_per_wg > 16)
         return fail("bad Jacobian launch geometry (%d workgroups x %d waves)",
                     desc->jac_wgs_per_block, desc->jac_waves_per_wg);
     int count = 0;

@@ -537,6 +537,8 @@ class ConstraintCollocator(object):
             jac_waves_per_wg=meta['kernels']['jac']['waves_per_wg'],
             fused_wgs_per_block=meta['kernels']['conjac']['wgs_per_block'],
             con_wgs_per_block=meta['kernels']['con']['wgs_per_block'],
+            fused_waves_per_wg=meta['kernels']['conjac']['waves_per_wg'],
+            con_waves_per_wg=meta['kernels']['con']['waves_per_wg'],
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
             device=self._device,

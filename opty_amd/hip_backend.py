@@ -119,7 +119,8 @@ class _Desc(ctypes.Structure):
             'n', 'M', 'm_known', 'q', 'p_known', 'r', 's', 'C', 'P', 'method',
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
-            'num_uniform', 'uniform_dynamic', 'device', 'layout')]
+            'num_uniform', 'uniform_dynamic', 'device', 'fused_waves_per_wg',
+            'con_waves_per_wg', 'layout')]
 
 
 class _ObjDesc(ctypes.Structure):

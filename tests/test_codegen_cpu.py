@@ -209,7 +209,8 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert lib.opty_hip_device_count() == 0
         desc = hb._Desc(N=10, n=1, M=1, C=2, P=2, jac_wgs_per_block=1,
                         fused_wgs_per_block=1, con_wgs_per_block=1,
-                        jac_waves_per_wg=1)
+                        jac_waves_per_wg=1, fused_waves_per_wg=1,
+                        con_waves_per_wg=1)
         handle = ctypes.c_void_p()
         rc = lib.opty_hip_create(ctypes.byref(desc), b'/nonexistent.hsaco',
                                  ctypes.byref(handle))
