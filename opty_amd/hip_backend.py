@@ -63,7 +63,7 @@ def build_runtime_library(force=False):
 
 
 def compile_module(source, cache_dir=None, show_compile_output=False,
-                   extra_flags=()):
+                   extra_flags=(), opt_level=None):
     """``hipcc --genco`` of a generated module; returns the ``.hsaco`` path.
 
     Cached on the SHA-256 of (source, device header, flags) the way the
@@ -79,7 +79,8 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     # node; -O1/-O2/-Os agree with the reference to 1e-13).  OPTY_HIPCC_OPT /
     # OPTY_HIPCC_FLAGS override for experiments.
     flags = ['--offload-arch=' + ARCH,
-             os.environ.get('OPTY_HIPCC_OPT', '-O2'), '-std=c++17'] + \
+             opt_level or os.environ.get('OPTY_HIPCC_OPT', '-O2'),
+             '-std=c++17'] + \
         os.environ.get('OPTY_HIPCC_FLAGS', '').split() + list(extra_flags)
     digest = hashlib.sha256(
         (source + '\0' + header + '\0' + ' '.join(flags)).encode()

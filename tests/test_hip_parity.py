@@ -452,7 +452,8 @@ def test_golden_window_embedded_at_full_size(name, N, layout):
 
 
 @pytest.mark.parametrize('name', ['config3_10link_small',
-                                  'elementary_mid_small'])
+                                  'elementary_mid_small',
+                                  'config5_standin_24link_small'])
 def test_optimisation_levels_agree(name, monkeypatch):
     """The same generated module built by hipcc at -O1 and at the default
     level goes through different compiler pipelines and must agree to
