@@ -42,7 +42,7 @@ def main():
     if os.environ.get('OPTY_TUNE_NODES'):
         fkw = dict(fkw, num_nodes=int(os.environ['OPTY_TUNE_NODES']))
     kw = factory(**fkw)
-    iters = 30
+    iters = int(os.environ.get('OPTY_TUNE_ITERS', 30))
     for spec in specs:
         opts = EmitOptions() if spec == 'default' else parse(spec)
         t0 = time.time()
