@@ -21,6 +21,11 @@ no data-path collective.  ``--gather`` adds the RCCL all-gather that
 reassembles the full constraint/Jacobian vectors (reported separately in
 ``config``).
 
+Timing: an untimed clock-ramp phase (``--prewarm-ms`` of the same step; an
+idle GPU starts at its lowest clock), W untimed warm-up steps, then exactly K
+steps between barrier + ``torch.cuda.synchronize()`` pairs, max over ranks.
+``--to-host`` adds the per-rank device-to-host copies (PCIe-inclusive rate).
+
 Prints ONE JSON line (rank 0).
 """
 
@@ -100,6 +105,9 @@ def main():
                          'own page-locked host buffer each step (the '
                          'PCIe-inclusive rate a host-side IPOPT sees; never '
                          'the headline value)')
+    ap.add_argument('--prewarm-ms', type=float, default=150.0,
+                    help='untimed clock-ramp phase before the warm-up steps '
+                         '(wall milliseconds of the same step; 0 disables)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -179,6 +187,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock ramp: an idle MI355X sits at its lowest shader clock and needs a
+    # few tens of milliseconds of work to reach the sustained one (the first
+    # ~150 steps run ~10 % slower).  The same step is therefore run untimed
+    # for `--prewarm-ms` of wall time before the W warm-up steps, so that the
+    # K timed steps measure the steady state whatever K and W are.
+    t_ramp = time.perf_counter()
+    k = 0
+    while (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
+        for _ in range(16):
+            step(k)
+            k += 1
+        torch.cuda.synchronize()
     for k in range(args.warmup):
         step(k)
     barrier()
@@ -253,6 +273,7 @@ def main():
                              'page-locked memory' if hosted is not None
                              else ''),
                 'oversubscribed': bool(oversub),
+                'prewarm_ms': args.prewarm_ms,
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
                 'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
