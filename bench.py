@@ -194,7 +194,13 @@ def main():
     # K timed steps measure the steady state whatever K and W are.
     t_ramp = time.perf_counter()
     k = 0
-    while (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
+    if gathered is not None and args.prewarm_ms > 0:
+        # steps contain collectives: every rank must run the same number
+        for k in range(256):
+            step(k)
+        torch.cuda.synchronize()
+    while gathered is None and \
+            (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
         for _ in range(16):
             step(k)
             k += 1
