@@ -105,11 +105,19 @@ def main():
                          'own page-locked host buffer each step (the '
                          'PCIe-inclusive rate a host-side IPOPT sees; never '
                          'the headline value)')
+    ap.add_argument('--streams', type=int, default=1,
+                    help='issue consecutive steps round-robin on this many '
+                         'HIP streams with separate output buffers, so that '
+                         'the drain of one evaluation overlaps the fill of '
+                         'the next (default 1: strictly one after the other, '
+                         'as an NLP solver calls them)')
     ap.add_argument('--prewarm-ms', type=float, default=150.0,
                     help='untimed clock-ramp phase before the warm-up steps '
                          '(wall milliseconds of the same step; 0 disables)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.streams > 1 and (args.gather or args.to_host):
+        ap.error('--streams > 1 is not combined with --gather / --to-host')
 
     import torch
     import torch.distributed as dist
@@ -158,6 +166,11 @@ def main():
              .to(dev) for s in range(4)]
     con = torch.empty(ncon, dtype=torch.float64, device=dev)
     jac = torch.empty(nnz, dtype=torch.float64, device=dev)
+    lanes = [(torch.cuda.current_stream(), con, jac)]
+    for _ in range(max(1, args.streams) - 1):
+        lanes.append((torch.cuda.Stream(device=dev),
+                      torch.empty(ncon, dtype=torch.float64, device=dev),
+                      torch.empty(nnz, dtype=torch.float64, device=dev)))
     gathered = None
     if args.gather and world > 1:
         gathered = (torch.empty(world*ncon, dtype=torch.float64, device=dev),
@@ -170,6 +183,9 @@ def main():
 
     def step(k):
         f = frees[k % len(frees)]
+        stream, con, jac = lanes[k % len(lanes)]
+        if len(lanes) > 1:
+            hip.set_stream(stream.cuda_stream)
         if args.serial:
             hip.eval_con(f, con, hb.DEVICE)
             hip.eval_jac(f, jac, hb.DEVICE)
@@ -221,10 +237,34 @@ def main():
     # Dominant kernel (opty_jac) duration, measured live with HIP events on
     # the stream the kernels are launched on.
     barrier()
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
     jac_ms = hip.time_eval(hb.EVAL_JAC, frees[0], None, jac, args.steps)
     con_ms = hip.time_eval(hb.EVAL_CON, frees[1], con, None, args.steps)
     fused_ms = hip.time_eval(hb.EVAL_FUSED, frees[2], con, jac, args.steps)
     barrier()
+
+    # Informational (rank 0, single GPU, not `value`): the same evaluations
+    # issued round-robin on two streams with two sets of output buffers, so
+    # that one launch's drain overlaps the next one's fill -- what a caller
+    # with independent points to evaluate gets, not what an NLP solver sees.
+    pipelined = None
+    if world == 1 and len(lanes) == 1 and not (args.gather or args.to_host):
+        s2 = torch.cuda.Stream(device=dev)
+        con2, jac2 = torch.empty_like(con), torch.empty_like(jac)
+        both = [(torch.cuda.current_stream(), con, jac), (s2, con2, jac2)]
+        def two_streams(count):
+            for k in range(count):
+                st, c_, j_ = both[k % 2]
+                hip.set_stream(st.cuda_stream)
+                hip.eval_con_jac(frees[k % len(frees)], c_, j_, hb.DEVICE)
+            torch.cuda.synchronize()
+
+        two_streams(max(args.warmup, 20))       # first touch of the buffers
+        tp = time.perf_counter()
+        two_streams(args.steps)
+        pipelined = args.steps/(time.perf_counter() - tp)
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        del con2, jac2
 
     if rank == 0:
         prog = col._build_program()
@@ -280,6 +320,8 @@ def main():
                              else ''),
                 'oversubscribed': bool(oversub),
                 'prewarm_ms': args.prewarm_ms,
+                'streams': len(lanes),
+                'two_stream_pipelined_evals_per_s': pipelined,
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
                 'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
