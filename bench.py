@@ -1,30 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: constraint + Jacobian evaluations per second of
 the 10-link pendulum on a cart at N = 100 000 collocation nodes (BASELINE.json
-metric, ``configs[2]``), inputs resident in HBM.
+metric, ``configs[2]`` on one GPU, ``configs[3]`` on several), inputs resident
+in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
 One *step* = one ``constraints(free)`` + one ``jacobian(free)`` on a free
 vector that differs from the previous step's (rotating set of synthetic
 vectors already in HBM), evaluated through the C ABI (``libopty_hip.so``) with
-device pointers on torch's current stream.  By default both outputs of a step
-come from ONE launch (``opty_hip_eval_con_jac``: the Jacobian waves plus one
-constraint wave per 64-node block); ``--serial`` issues ``opty_hip_eval_con``
-then ``opty_hip_eval_jac`` instead.
+device pointers on torch's current stream.  Both outputs of a step come from
+ONE launch (``opty_hip_eval_con_jac`` / ``opty_hip_eval_shard``: the Jacobian
+waves plus one constraint wave per 64-node block); ``--serial`` issues two
+launches (constraints, then Jacobian -- the order IPOPT calls them in)
+instead, and the default run also reports that figure as
+``config.serial_evals_per_s``.
 
-Multi-GPU (``--gpus N`` under ``torch.distributed.run``): the collocation
-nodes are sharded, one contiguous node range per rank with a one-node halo
-(SURVEY.md 8(e)); every rank owns 100 000 nodes of an N x 100 000-node problem
-(weak scaling) and leaves its slice of the outputs in its own HBM -- there is
-no data-path collective.  ``--gather`` adds the RCCL all-gather that
-reassembles the full constraint/Jacobian vectors (reported separately in
-``config``).
+Multi-GPU (``--gpus N`` under ``torch.distributed.run``) is BASELINE config 4:
+the 100 000 nodes of ONE problem are sharded over the ranks, one contiguous
+node range each with a one-node halo (``opty_amd.sharded``) --
+**strong scaling**, ``value`` = evaluations of the whole problem per second
+with every rank's slice of the outputs left in its own HBM (no data-path
+collective).  The same K steps are then re-timed with the two re-assembly
+variants SURVEY.md 8(e) lists, reported in ``config.variants``:
+``gather`` (+ RCCL point-to-point gather-v of constraints and Jacobian to rank
+0) and ``to_host`` (+ every rank copying its shard over its own PCIe link
+into one page-locked host vector shared by all ranks).  ``--weak`` instead
+gives every rank its own ``--nodes``-node problem.
 
 Timing: an untimed clock-ramp phase (``--prewarm-ms`` of the same step; an
 idle GPU starts at its lowest clock), W untimed warm-up steps, then exactly K
 steps between barrier + ``torch.cuda.synchronize()`` pairs, max over ranks.
-``--to-host`` adds the per-rank device-to-host copies (PCIe-inclusive rate).
 
 Prints ONE JSON line (rank 0).
 """
@@ -35,6 +41,11 @@ import os
 import sys
 import time
 
+# the CPU baseline's OpenMP team is pinned; libgomp reads
+# these when it is loaded, i.e. before `import torch`
+os.environ.setdefault('OMP_PROC_BIND', 'close')
+os.environ.setdefault('OMP_PLACES', 'cores')
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
@@ -44,45 +55,206 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 WORKLOAD = 'config3_10link'
 
 
-def cpu_baseline(kw, budget_s=14.0):
-    """The oracle's C/OpenMP restatement of the reference's generated code,
-    timed on this box's host cores on a bounded number of repetitions of the
-    same N = 100 000 workload, for a few OpenMP team sizes; the best one is
-    reported (``cores`` = its thread count)."""
-    from oracle.collocation_oracle import OracleCollocator
+def host_cpu():
+    """CPU model, sockets, physical cores, logical CPUs and NUMA nodes of this
+    box (for ``cpu_baseline.sample``)."""
+    model, phys, logical = '?', set(), 0
+    try:
+        pid = cid = None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                k, _, v = line.partition(':')
+                k, v = k.strip(), v.strip()
+                if k == 'model name':
+                    model = v
+                elif k == 'processor':
+                    logical += 1
+                elif k == 'physical id':
+                    pid = v
+                elif k == 'core id':
+                    cid = v
+                elif not k and pid is not None:
+                    phys.add((pid, cid))
+                    pid = cid = None
+    except OSError:
+        pass
+    try:
+        numa = len([d for d in os.listdir('/sys/devices/system/node')
+                    if d.startswith('node') and d[4:].isdigit()])
+    except OSError:
+        numa = 0
+    return dict(model=model, sockets=len({p for p, _ in phys}) or 1,
+                physical_cores=len(phys) or logical,
+                logical_cpus=logical or (os.cpu_count() or 1),
+                numa_nodes=numa)
+
+
+def cpu_baseline(kw, budget_s=24.0):
+    """The oracle's C/OpenMP restatement of the reference's generated code
+    (validated against the real reference's wall time on the same cores by
+    ``tests/golden/_gen/time_reference.py``), timed on this box's host cores
+    on the same N = 100 000 workload: OpenMP team sizes 1 and a few up to the
+    physical core count, threads bound (``OMP_PROC_BIND=close``,
+    ``OMP_PLACES=cores``), fresh ``free`` each repetition, min and median per
+    team.  ``value`` is the best team's *reference-shaped* pair (fresh
+    constraint array + transpose copy, as ``opty/direct_collocation.py:
+    2444-2446``); the persistent-buffer variant is reported beside it."""
+    import numpy as np
+    from oracle.collocation_oracle import OracleCollocator, split_free
     from opty_amd import problems
-    ncpu = os.cpu_count() or 1
+    cpu = host_cpu()
+    cores = cpu['physical_cores']
     orc = OracleCollocator(name='config3_10link', parallel=True, **kw)
     con = orc.generate_constraint_function()
     jac = orc.generate_jacobian_function()
     frees = [problems.make_free(orc.num_free, seed=s) for s in range(3)]
     con(frees[0]), jac(frees[0])                   # warm-up / page-in
-    teams = sorted({t for t in (1, 16, ncpu//4, ncpu//2, ncpu) if t >= 1})
+
+    # persistent-buffer variant: the compiled loops called directly on
+    # preallocated outputs (no fresh array, no transpose copy)
+    pcon = np.empty((orc.N - 1, orc.M))
+    pjac = np.empty((orc.N - 1, orc.M*orc.C))
+    consts = [float(orc.known_parameter_map[p]) for p in orc.parameters]
+
+    def persistent(free):
+        states, spec, _, _ = split_free(free, orc.n, orc.q, orc.N, False)
+        vec = orc._node_vectors(states, np.atleast_2d(spec))
+        orc._c_con(pcon, *vec, *consts, orc.node_time_interval)
+        orc._c_jac(pjac, *vec, *consts, orc.node_time_interval)
+
+    def shaped(free):
+        con(free)
+        jac(free)
+
+    teams = sorted({t for t in (1, 8, 16, 32, cores//2, cores) if 1 <= t <=
+                    max(1, cores)})
     results = {}
+    per_team = budget_s/(2*len(teams))
     for threads in teams:
         orc._c_con.parallel = orc._c_jac.parallel = threads
-        con(frees[1]), jac(frees[1])
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            f = frees[reps % 3]
-            con(f)
-            jac(f)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > budget_s/len(teams) or reps >= 100:
-                break
-        results[threads] = (reps/el, reps)
-    best = max(results, key=lambda t: results[t][0])
-    detail = ', '.join('%d thr: %.1f/s (%d reps)' % (t, results[t][0],
-                                                      results[t][1])
-                       for t in teams)
-    return dict(value=results[best][0], unit='evals/s', cores=best,
-                kind='port',
-                sample='constraint+Jacobian evaluations of the full '
-                       'N=%d 10-link problem, OpenMP over nodes ' % orc.N +
-                       '(gcc -O2 -fopenmp), reference-shaped wrappers '
-                       '(fresh con array + transpose copy); ' + detail)
+        for label, fn in (('shaped', shaped), ('persistent', persistent)):
+            for k in range(3):
+                fn(frees[k])                       # 3 warm-ups
+            ts = []
+            t_end = time.perf_counter() + per_team
+            while len(ts) < 20 or (time.perf_counter() < t_end and
+                                   len(ts) < 60):
+                f = frees[len(ts) % 3]
+                t0 = time.perf_counter()
+                fn(f)
+                ts.append(time.perf_counter() - t0)
+                if len(ts) >= 5 and time.perf_counter() > t_end + per_team:
+                    break                          # a very slow team
+            ts.sort()
+            results[(threads, label)] = (ts[0], ts[len(ts)//2], len(ts))
+    best = min(teams, key=lambda t: results[(t, 'shaped')][1])
+    best_p = min(teams, key=lambda t: results[(t, 'persistent')][1])
+    detail = '; '.join(
+        '%d thr: shaped min %.1f / med %.1f ms, persistent min %.1f / med '
+        '%.1f ms (%d reps)' % (
+            t, 1e3*results[(t, 'shaped')][0], 1e3*results[(t, 'shaped')][1],
+            1e3*results[(t, 'persistent')][0],
+            1e3*results[(t, 'persistent')][1], results[(t, 'shaped')][2])
+        for t in teams)
+    return dict(
+        value=1.0/results[(best, 'shaped')][1], unit='evals/s', cores=best,
+        kind='port', stat='median',
+        min_ms=1e3*results[(best, 'shaped')][0],
+        median_ms=1e3*results[(best, 'shaped')][1],
+        persistent_buffers={'evals_per_s':
+                            1.0/results[(best_p, 'persistent')][1],
+                            'cores': best_p,
+                            'min_ms': 1e3*results[(best_p, 'persistent')][0],
+                            'median_ms':
+                            1e3*results[(best_p, 'persistent')][1]},
+        host=cpu,
+        sample='constraint+Jacobian evaluations of the full N=%d 10-link '
+               'problem (same workload as the GPU line), OpenMP over nodes '
+               '(gcc -O2 -fopenmp, OMP_PROC_BIND=%s OMP_PLACES=%s), 3 '
+               'warm-ups then >= 20 repetitions per team, fresh free each; '
+               'value = 1/median of the reference-shaped pair of the best '
+               'team; CPU: %s, %d socket(s), %d physical cores, %d logical, '
+               '%d NUMA node(s); %s' % (
+                   orc.N, os.environ.get('OMP_PROC_BIND'),
+                   os.environ.get('OMP_PLACES'), cpu['model'],
+                   cpu['sockets'], cpu['physical_cores'],
+                   cpu['logical_cpus'], cpu['numa_nodes'], detail))
+
+
+def lookup_traffic(sha, kernel):
+    """HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    collected separately with rocprofv3 as the microarch guide prescribes;
+    summaries under profiles/), keyed on the sha-256 of the generated module
+    the counters were collected on: a changed kernel yields ``None``."""
+    try:
+        with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
+            return json.load(f)[sha][kernel]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def other_configs(dev, iters):
+    """Kernel times and HBM fractions of BASELINE config 2 and of the
+    config-5 stand-in on this GPU (hipEvent-timed, single GPU)."""
+    import torch
+    import opty_amd
+    from opty_amd import problems, hip_backend as hb
+    out = {}
+    for name in ('config2_pendulum', 'config5_standin_24link'):
+        col = opty_amd.ConstraintCollocator(device=dev.index,
+                                            **problems.build(name))
+        hip = col.hip
+        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        free = torch.from_numpy(problems.make_free(
+            col.num_free, variable_duration=col._variable_duration)).to(dev)
+        con = torch.empty(col.num_constraints, dtype=torch.float64,
+                          device=dev)
+        jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+        res = {}
+        for what, label in ((hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC,
+                                                        'opty_jac'),
+                            (hb.EVAL_FUSED, 'opty_conjac')):
+            hip.time_eval(what, free, con, jac, max(3, iters//4))
+            res[label] = hip.time_eval(what, free, con, jac, iters)
+        nbytes = 8.0*(col.num_free + col.num_constraints + hip.nnz)
+        out[name] = dict(
+            nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
+            fused_algorithmic_bytes=nbytes,
+            fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
+        hip.close()
+        del con, jac, free
+        torch.cuda.empty_cache()
+    return out
+
+
+def host_path(kw, dev_index, reps=7):
+    """Wall time of the host (cyipopt-callback) path of config 3: NumPy in,
+    NumPy out through ``generate_*_function`` (PCIe inclusive), for the
+    reference's dense-block pattern and for ``prune_zeros=True``."""
+    import opty_amd
+    from opty_amd import problems
+
+    def med(fn, frees):
+        fn(frees[0])
+        ts = []
+        for k in range(reps):
+            t0 = time.perf_counter()
+            fn(frees[k % len(frees)])
+            ts.append(time.perf_counter() - t0)
+        return 1e3*sorted(ts)[len(ts)//2]
+
+    out = {}
+    for label, extra in (('', {}), ('_pruned', {'prune_zeros': True})):
+        col = opty_amd.ConstraintCollocator(device=dev_index, **extra, **kw)
+        frees = [problems.make_free(col.num_free, seed=s) for s in range(3)]
+        if not label:
+            out['con'] = med(col.generate_constraint_function(), frees)
+        out['jac' + label] = med(col.generate_jacobian_function(), frees)
+        out['nnz' + label] = col.hip.nnz
+        col.hip.close()
+    out['pair_evals_per_s'] = 1e3/(out['con'] + out['jac'])
+    out['pair_pruned_evals_per_s'] = 1e3/(out['con'] + out['jac_pruned'])
+    return out
 
 
 def main():
@@ -90,39 +262,30 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--nodes', type=int, default=100000)
-    ap.add_argument('--gather', action='store_true',
-                    help='all-gather the sharded outputs over RCCL each step')
+    ap.add_argument('--nodes', type=int, default=100000,
+                    help='collocation nodes of the problem (sharded over the '
+                         'ranks; per rank with --weak)')
+    ap.add_argument('--weak', action='store_true',
+                    help='weak scaling: every rank evaluates its own '
+                         '--nodes-node problem (default: strong scaling, ONE '
+                         '--nodes-node problem sharded over the ranks = '
+                         'BASELINE config 4)')
     ap.add_argument('--serial', action='store_true',
-                    help='two launches per step (opty_hip_eval_con, then '
-                         'opty_hip_eval_jac) instead of opty_hip_eval_con_jac')
-    ap.add_argument('--strong', action='store_true',
-                    help='strong scaling: --nodes is the GLOBAL node count, '
-                         'sharded over the ranks (default: weak scaling, '
-                         '--nodes per rank)')
-    ap.add_argument('--to-host', action='store_true',
-                    help='every rank also copies its con/jac shard into its '
-                         'own page-locked host buffer each step (the '
-                         'PCIe-inclusive rate a host-side IPOPT sees; never '
-                         'the headline value)')
-    ap.add_argument('--streams', type=int, default=1,
-                    help='issue consecutive steps round-robin on this many '
-                         'HIP streams with separate output buffers, so that '
-                         'the drain of one evaluation overlaps the fill of '
-                         'the next (default 1: strictly one after the other, '
-                         'as an NLP solver calls them)')
+                    help='two launches per step (constraints, then Jacobian) '
+                         'instead of the fused one')
     ap.add_argument('--prewarm-ms', type=float, default=150.0,
                     help='untimed clock-ramp phase before the warm-up steps '
                          '(wall milliseconds of the same step; 0 disables)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the secondary figures (serial pair, host path, '
+                         'other configs, re-assembly variants)')
     args = ap.parse_args()
-    if args.streams > 1 and (args.gather or args.to_host):
-        ap.error('--streams > 1 is not combined with --gather / --to-host')
 
     import torch
     import torch.distributed as dist
     from opty_amd import problems, hip_backend as hb
-    import opty_amd
+    from opty_amd.sharded import ShardedCollocator, SharedHostVector
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -145,155 +308,143 @@ def main():
                 'cuda', local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    strong = not args.weak
 
     factory, fkw = problems.CONFIGS[WORKLOAD]
-    local_nodes = args.nodes
-    if args.strong and world > 1:
-        # contiguous node ranges with a one-node halo (opty_amd.sharded)
-        from opty_amd.sharded import partition_nodes
-        a, b = partition_nodes(args.nodes - 1, world)[rank]
-        local_nodes = b - a + 1
-    fkw = dict(fkw, num_nodes=local_nodes)
-    kw = factory(**fkw)
-    # every rank evaluates its own 100 000-node shard (nodes rank*N .. +N,
-    # with its one-node halo, is exactly an N-node collocation problem)
-    col = opty_amd.ConstraintCollocator(device=local_rank, **kw)
+    kw = factory(**dict(fkw, num_nodes=args.nodes))
+    # Strong scaling: the handle is built for the global problem and
+    # evaluates this rank's node range of it.  Weak scaling (and one GPU):
+    # the rank's range is the whole problem.
+    sh = ShardedCollocator(rank=rank if strong else 0,
+                           world_size=world if strong else 1,
+                           device=dev, **kw)
+    col = sh.collocator
     hip = col.hip
     hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    a, b = sh.a, sh.b
+    M, P, N = sh.M, sh.P, sh.N
+    nfree = col.num_free
 
-    nfree, ncon, nnz = col.num_free, col.num_constraints, hip.nnz
-    frees = [torch.from_numpy(problems.make_free(nfree, seed=1000*rank + s))
-             .to(dev) for s in range(4)]
-    con = torch.empty(ncon, dtype=torch.float64, device=dev)
-    jac = torch.empty(nnz, dtype=torch.float64, device=dev)
-    lanes = [(torch.cuda.current_stream(), con, jac)]
-    for _ in range(max(1, args.streams) - 1):
-        lanes.append((torch.cuda.Stream(device=dev),
-                      torch.empty(ncon, dtype=torch.float64, device=dev),
-                      torch.empty(nnz, dtype=torch.float64, device=dev)))
-    gathered = None
-    if args.gather and world > 1:
-        gathered = (torch.empty(world*ncon, dtype=torch.float64, device=dev),
-                    torch.empty(world*nnz, dtype=torch.float64, device=dev))
+    frees = [torch.from_numpy(problems.make_free(
+        nfree, seed=s + (0 if strong else 1000*rank))).to(dev)
+        for s in range(4)]
+    con, jac = sh.con_local, sh.jac_local           # (M, b-a), ((b-a)*P,)
+    cs = con.stride(0)
+    # raw addresses: the step is one ctypes call
+    fp = [f.data_ptr() for f in frees]
+    cp, jp = con.data_ptr(), jac.data_ptr()
 
-    hosted = None
-    if args.to_host:
-        hosted = (torch.empty(ncon, dtype=torch.float64).pin_memory(),
-                  torch.empty(nnz, dtype=torch.float64).pin_memory())
-
-    def step(k):
-        f = frees[k % len(frees)]
-        stream, con, jac = lanes[k % len(lanes)]
-        if len(lanes) > 1:
-            hip.set_stream(stream.cuda_stream)
-        if args.serial:
-            hip.eval_con(f, con, hb.DEVICE)
-            hip.eval_jac(f, jac, hb.DEVICE)
+    def step(k, serial=args.serial):
+        f = fp[k % 4]
+        if serial:
+            hip.eval_shard(hb.EVAL_CON, f, cp, cs, None, a, b)
+            hip.eval_shard(hb.EVAL_JAC, f, None, cs, jp, a, b)
         else:
-            hip.eval_con_jac(f, con, jac, hb.DEVICE)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered[0], con)
-            dist.all_gather_into_tensor(gathered[1], jac)
-        if hosted is not None:
-            hosted[0].copy_(con, non_blocking=True)
-            hosted[1].copy_(jac, non_blocking=True)
+            hip.eval_shard(hb.EVAL_FUSED, f, cp, cs, jp, a, b)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, steps, warmup):
+        for k in range(warmup):
+            fn(k)
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            fn(k)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
+
     # Clock ramp: an idle MI355X sits at its lowest shader clock and needs a
-    # few tens of milliseconds of work to reach the sustained one (the first
-    # ~150 steps run ~10 % slower).  The same step is therefore run untimed
-    # for `--prewarm-ms` of wall time before the W warm-up steps, so that the
-    # K timed steps measure the steady state whatever K and W are.
+    # few tens of milliseconds of work to reach the sustained one.  The same
+    # step is run untimed for `--prewarm-ms` of wall time before the W
+    # warm-up steps, so that the K timed steps measure the steady state
+    # whatever K and W are.
     t_ramp = time.perf_counter()
     k = 0
-    if gathered is not None and args.prewarm_ms > 0:
-        # steps contain collectives: every rank must run the same number
-        for k in range(256):
-            step(k)
-        torch.cuda.synchronize()
-    while gathered is None and \
-            (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
+    while (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
         for _ in range(16):
             step(k)
             k += 1
         torch.cuda.synchronize()
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = timed(step, args.steps, args.warmup)
 
-    # Dominant kernel (opty_jac) duration, measured live with HIP events on
-    # the stream the kernels are launched on.
-    barrier()
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
-    jac_ms = hip.time_eval(hb.EVAL_JAC, frees[0], None, jac, args.steps)
-    con_ms = hip.time_eval(hb.EVAL_CON, frees[1], con, None, args.steps)
-    fused_ms = hip.time_eval(hb.EVAL_FUSED, frees[2], con, jac, args.steps)
+    # Kernel durations, measured live with HIP events on the launch stream.
+    jac_ms = hip.time_eval_shard(hb.EVAL_JAC, frees[0], None, cs, jac, a, b,
+                                 args.steps)
+    con_ms = hip.time_eval_shard(hb.EVAL_CON, frees[1], con, cs, None, a, b,
+                                 args.steps)
+    fused_ms = hip.time_eval_shard(hb.EVAL_FUSED, frees[2], con, cs, jac, a,
+                                   b, args.steps)
     barrier()
 
-    # Informational (rank 0, single GPU, not `value`): the same evaluations
-    # issued round-robin on two streams with two sets of output buffers, so
-    # that one launch's drain overlaps the next one's fill -- what a caller
-    # with independent points to evaluate gets, not what an NLP solver sees.
-    pipelined = None
-    if world == 1 and len(lanes) == 1 and not (args.gather or args.to_host):
-        s2 = torch.cuda.Stream(device=dev)
-        con2, jac2 = torch.empty_like(con), torch.empty_like(jac)
-        both = [(torch.cuda.current_stream(), con, jac), (s2, con2, jac2)]
-        def two_streams(count):
-            for k in range(count):
-                st, c_, j_ = both[k % 2]
-                hip.set_stream(st.cuda_stream)
-                hip.eval_con_jac(frees[k % len(frees)], c_, j_, hb.DEVICE)
-            torch.cuda.synchronize()
+    extras = {}
+    if not args.no_extras:
+        if not args.serial:
+            el = timed(lambda k: step(k, True), args.steps, args.warmup)
+            extras['serial_evals_per_s'] = args.steps*(
+                1 if strong else world)/el
+        if world > 1 and strong:
+            # re-assembly variants of SURVEY.md 8(e); rank 0 is where IPOPT
+            # would run and evaluates its own shard in place
+            variants = {}
+            ncn = N - 1
 
-        two_streams(max(args.warmup, 20))       # first touch of the buffers
-        tp = time.perf_counter()
-        two_streams(args.steps)
-        pipelined = args.steps/(time.perf_counter() - tp)
-        hip.set_stream(torch.cuda.current_stream().cuda_stream)
-        del con2, jac2
+            def gather_step(k):
+                sh.evaluate(frees[k % 4], in_place=(rank == 0))
+                sh.gather(0)
+            el = timed(gather_step, args.steps, args.warmup)
+            variants['gather'] = {
+                'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
+                'what': 'eval + point-to-point gather-v of con and jac to '
+                        'rank 0 (%s)' % dist.get_backend()}
+            con_host = SharedHostVector('opty_bench_con_%d' % os.getppid(),
+                                        M*ncn, rank)
+            jac_host = SharedHostVector('opty_bench_jac_%d' % os.getppid(),
+                                        P*ncn, rank)
+
+            def host_step(k):
+                sh.evaluate(frees[k % 4])
+                sh.to_host(con_host, jac_host)
+            el = timed(host_step, args.steps, args.warmup)
+            variants['to_host'] = {
+                'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
+                'what': 'eval + every rank copies its shard over its own '
+                        'PCIe link into one page-locked host vector shared '
+                        'by all ranks'}
+            extras['variants'] = variants
+            con_host.close()
+            jac_host.close()
+        if world == 1:
+            extras['other_configs'] = other_configs(dev, max(20,
+                                                             args.steps//4))
+            extras['host_path_ms'] = host_path(kw, local_rank)
 
     if rank == 0:
-        prog = col._build_program()
-        P, M, N = prog.P, prog.M, local_nodes
-        # algorithmic bytes of one Jacobian launch: read
-        # `free` once, write the dense blocks once
-        jac_bytes = 8.0*nfree + 8.0*P*(N - 1)
-        con_bytes = 8.0*nfree + 8.0*M*(N - 1)
+        cnt = b - a
+        free_bytes = 8.0*((col.num_states +
+                           col.num_unknown_input_trajectories)*(cnt + 1))
+        # algorithmic bytes of one launch: read the free
+        # columns of the launch's nodes once, write the outputs once
+        jac_bytes = free_bytes + 8.0*P*cnt
+        con_bytes = free_bytes + 8.0*M*cnt
         if args.serial:
             dom, dom_ms, dom_bytes = 'opty_jac', jac_ms, jac_bytes
-        else:   # one launch reads `free` once and writes both outputs
+        else:
             dom, dom_ms = 'opty_conjac', fused_ms
-            dom_bytes = 8.0*nfree + 8.0*M*(N - 1) + 8.0*P*(N - 1)
+            dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
         achieved = dom_bytes/(dom_ms*1e-3)/1e9
-        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-        # collected separately with rocprofv3 as the microarch guide
-        # prescribes; summaries under profiles/)
-        traffic = None
-        try:
-            # the counters were collected on the 100 000-node launch
-            if N == 100000:
-                with open(os.path.join(REPO, 'profiles',
-                                       'traffic.json')) as f:
-                    traffic = json.load(f)[dom]['hbm_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
-        # weak scaling: every rank evaluates a full N-node problem per step;
-        # strong scaling: all ranks together evaluate one
-        value = args.steps*(1 if args.strong else world)/elapsed
+        traffic = lookup_traffic(col._kernel_meta['sha'], dom) \
+            if (world == 1 and args.nodes == 100000) else None
+        value = args.steps*(1 if strong else world)/elapsed
+        nnz_total = P*(N - 1)*(1 if strong else world)
         out = {
             'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
                       '(10-link pendulum on cart, backward Euler)',
@@ -301,33 +452,35 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3*elapsed/args.steps,
             'higher_is_better': True,
-            'scaling': 'strong' if args.strong else 'weak',
+            'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {
-                'workload': '10-link inverted pendulum on cart, %d nodes per '
-                            'GPU, backward Euler, n=M=22, q=1, C=45, nnz=%d '
-                            'per GPU' % (N, nnz),
-                'step': ('opty_hip_eval_con + opty_hip_eval_jac (two '
-                         'launches)' if args.serial else
-                         'opty_hip_eval_con_jac (constraints and Jacobian of '
-                         'one free vector from one launch)'),
-                'sharding': 'nodes sharded one contiguous range per GPU, '
-                            'outputs left distributed' +
-                            (', + RCCL all-gather of con and jac'
-                             if gathered is not None else '') +
-                            (', + device-to-host copy of every shard into '
-                             'page-locked memory' if hosted is not None
-                             else ''),
+                'workload': (
+                    '10-link inverted pendulum on cart, %d nodes%s, backward '
+                    'Euler, n=M=22, q=1, C=45, nnz=%d' % (
+                        N, ' per GPU' if not strong else
+                        (' sharded over %d GPUs (BASELINE config 4)' % world
+                         if world > 1 else ''), nnz_total)),
+                'step': ('constraints then Jacobian, two launches'
+                         if args.serial else
+                         'constraints and Jacobian of one free vector from '
+                         'one launch (opty_hip_eval_shard / '
+                         'opty_hip_eval_con_jac)'),
+                'sharding': (
+                    'ONE problem, constraint nodes [%d, %d) of %d on rank 0 '
+                    '(contiguous ranges, one-node halo); outputs left '
+                    'distributed, no data-path collective' % (a, b, N - 1)
+                    if strong else
+                    'independent %d-node problems, one per GPU' % N),
                 'oversubscribed': bool(oversub),
                 'prewarm_ms': args.prewarm_ms,
-                'streams': len(lanes),
-                'two_stream_pipelined_evals_per_s': pipelined,
+                'code_object_sha': col._kernel_meta['sha'][:16],
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
-                'jac_GBps_nnz_written': 8.0*P*(N - 1)/(jac_ms*1e-3)/1e9,
+                'GBps_nnz_written': 8.0*P*cnt/(jac_ms*1e-3)/1e9,
                 'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
                               'opty_conjac': fused_ms},
-                'pair_algorithmic_GB': (jac_bytes + con_bytes)/1e9,
+                'nodes_per_launch': cnt,
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
@@ -335,6 +488,7 @@ def main():
                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
         }
+        out['config'].update(extras)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(kw)
         print(json.dumps(out))

@@ -98,7 +98,9 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
 int opty_hip_destroy(opty_hip_problem *p);
 
 /* Use an existing hipStream_t (e.g. torch's current stream) for all work of
- * this handle; NULL restores the handle's own stream. */
+ * this handle; NULL restores the handle's own stream.  A handle's device
+ * state belongs to one stream at a time: work issued after a switch is
+ * ordered behind everything the handle enqueued on the previous stream. */
 int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream);
 int opty_hip_synchronize(opty_hip_problem *p);
 
@@ -162,12 +164,46 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
                                     int64_t node_offset, int64_t *rows,
                                     int64_t *cols, int32_t mem);
 
+/* Global indices of the values opty_hip_eval_shard writes for the constraint
+ * nodes [node_begin, node_end) of this handle's problem: (node_end -
+ * node_begin)*P int64 each. */
+int opty_hip_jacobian_indices_range(opty_hip_problem *p, int64_t node_begin,
+                                    int64_t node_end, int64_t *rows,
+                                    int64_t *cols, int32_t mem);
+
 /* Runs `iters` evaluations back to back on the handle's stream with device
  * buffers and returns the mean milliseconds per evaluation measured with
  * hipEvents recorded on that stream. */
 int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
                        double *con, double *jac, int32_t iters,
                        float *ms_per_iter);
+
+/* ---- node shards (one process per GPU) ----------------------
+ * Evaluates the constraint nodes [node_begin, node_end) of the handle's
+ * problem from the GLOBAL free vector (device memory; only the time-node
+ * columns [node_begin, node_end] of its trajectory rows and its parameter tail
+ * are read -- the one-node halo of opty/direct_collocation.py:2411-2413).
+ * Device pointers only:
+ *   con : the shard's value of equation j, node i goes to
+ *         con[j*con_stride + (i - node_begin)]; con_stride = N-1 with
+ *         con = global_con + node_begin writes the shard in place into the
+ *         global equation-major vector (opty/direct_collocation.py:2446),
+ *         con_stride = node_end - node_begin gives a dense (M x nodes) block;
+ *   jac : the shard's blocks, jac[(i - node_begin)*P + e]; jac =
+ *         global_jac + node_begin*P is the contiguous slice
+ *         [node_begin*P, node_end*P) of the global node-major vector
+ *         (opty/direct_collocation.py:2885-2887).
+ * `what` is OPTY_HIP_EVAL_*.  Problems with instance constraints and the CSR
+ * layout are not sharded. */
+int opty_hip_eval_shard(opty_hip_problem *p, int32_t what, const double *free,
+                        double *con, int64_t con_stride, double *jac,
+                        int64_t node_begin, int64_t node_end);
+/* opty_hip_time_eval for a shard. */
+int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
+                             const double *free, double *con,
+                             int64_t con_stride, double *jac,
+                             int64_t node_begin, int64_t node_end,
+                             int32_t iters, float *ms_per_iter);
 
 /* ---- objective and objective gradient -------------
  * Device counterpart of create_objective_function (opty/utils.py:329-470):
@@ -198,6 +234,11 @@ int opty_hip_objective_eval(opty_hip_objective *o, const double *free,
  * opty/direct_collocation.py:2814) are copied back at full PCIe rate. */
 void *opty_hip_host_alloc(size_t bytes);
 int opty_hip_host_free(void *ptr);
+/* Page-locks memory the caller already owns -- e.g. a shared-memory mapping
+ * of the one host vector that IPOPT reads and into which every rank copies its
+ * node shard over its own PCIe link ("direct-to-host"). */
+int opty_hip_host_register(void *ptr, size_t bytes);
+int opty_hip_host_unregister(void *ptr);
 
 int opty_hip_device_count(void);
 const char *opty_hip_last_error(void);

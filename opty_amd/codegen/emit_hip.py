@@ -45,6 +45,9 @@ CSR_MAX_ROW = 64
 #: workgroups the runtime launches opty_uni with (OPTY_UNI_WORKGROUPS in
 #: opty_hip.cpp)
 UNI_WORKGROUPS = 16
+#: waves an MI355X holds at once when a CU takes four of these kernels' waves
+#: (256 CUs x 4 SIMDs; one wave per SIMD at their register footprint)
+RESIDENT_WAVES = 1024
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -845,10 +848,32 @@ class _ModuleWriter(object):
         return '\n'.join(src), dict(name='opty_inst', groups=1, lds_bytes=0)
 
 
-def emit_module(prog, opts=None):
+def _fit_one_round(auto_groups, con_waves, node_blocks):
+    """Strip count for a launch of ``node_blocks`` 64-node blocks.
+
+    A launch whose waves are all resident at once finishes in one round; one
+    that needs 1.3 rounds takes almost as long as two.  Measured on MI355X
+    (10-link pendulum, 12 500 nodes = 196 blocks -- one of 8 node shards of
+    BASELINE config 4, profiles/r02_shard_strips.txt): 6 strips + 1
+    constraint wave per block = 1372 waves, 0.0253 ms; 4 strips + 1 = 980
+    waves <= 1024, 0.0233 ms.  Coarser strips cost registers (4 strips: 298
+    VGPRs, still no scratch), so the count only goes down to 60 % of what the
+    register-pressure rule picked, and only when that makes the launch fit."""
+    if not node_blocks or node_blocks*(auto_groups + con_waves) \
+            <= RESIDENT_WAVES:
+        return auto_groups
+    for g in range(auto_groups - 1, max(2, -(-3*auto_groups//5)) - 1, -1):
+        if node_blocks*(g + con_waves) <= RESIDENT_WAVES:
+            return g
+    return auto_groups
+
+
+def emit_module(prog, opts=None, node_blocks=None):
     """Returns ``(source, meta)``; ``meta`` describes the launch geometry the
     runtime needs (waves per node block, size of the ``uni`` table, whether
-    the table depends on ``free``)."""
+    the table depends on ``free``).  ``node_blocks``: 64-node blocks of the
+    launches this module is built for (picks the strip count of small
+    launches, see ``_fit_one_round``); None = large launches."""
     opts = opts or EmitOptions()
     w = _ModuleWriter(prog, opts)
     groups = w.group_ranges()
@@ -874,6 +899,14 @@ def emit_module(prog, opts=None):
             if worst <= opts.max_live + 5 or len(con_sets) >= prog.M:
                 break
             parts += 1
+    if opts.groups is None and node_blocks:
+        fit = _fit_one_round(len(groups), len(con_sets), int(node_blocks))
+        if fit != len(groups):
+            import copy
+            opts = copy.copy(opts)
+            opts.groups = fit
+            w = _ModuleWriter(prog, opts)
+            groups = w.group_ranges()
     con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra

@@ -157,7 +157,8 @@ struct opty_hip_problem {
     double h = 0.0;
     bool have_params = false, have_known = false, have_inst = false,
          have_h = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the last enqueued work
 
     int64_t ncon_nodes() const { return d.N - 1; }
     int64_t P() const { return (int64_t)d.P; }
@@ -189,11 +190,38 @@ int check_ready(const opty_hip_problem *p) {
     return 0;
 }
 
+struct NodeRange {
+    long long begin, end, con_stride;
+};
+
+NodeRange whole(const opty_hip_problem *p) {
+    return NodeRange{0, p->ncon_nodes(), p->ncon_nodes()};
+}
+
+// A handle's device state (node-invariant table, staging buffers) belongs to
+// one stream at a time.  When the caller moved the handle to another stream
+// (opty_hip_set_stream), work issued there is ordered after everything the
+// handle enqueued on the previous one: opty_uni may overwrite the table that
+// kernels of the previous stream still read, and the first fill has to be
+// visible to the new stream.
+int order_streams(opty_hip_problem *p) {
+    if (p->last_stream && p->last_stream != p->stream) {
+        HIP_TRY(hipEventRecord(p->ev_order, p->last_stream));
+        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_order, 0));
+    }
+    p->last_stream = p->stream;
+    return 0;
+}
+
 // wgs_per_block: workgroups per 64-node block (0: a single one-wave launch,
 // < 0: that many workgroups regardless of the node count); threads: workgroup
 // size.
+// The launch evaluates the constraint nodes [begin, end) of the handle's
+// problem: `con` points at the shard's first value of equation 0 (equations
+// are `con_stride` doubles apart), `jac` at the shard's first block.
 int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
-           int threads, const double *free_, double *con, double *jac) {
+           int threads, const double *free_, double *con, double *jac,
+           const NodeRange &rg) {
     KernelArgs a;
     a.free_ = free_;
     a.known_traj = p->d_known;
@@ -201,13 +229,14 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
     a.uni_c = p->d_uni;
     a.uni_w = p->d_uni;
     a.inst_idx = p->d_inst_idx;
-    a.con = con;
+    // the kernels index con with the global node number
+    a.con = con ? con - rg.begin : nullptr;
     a.jac = jac;
     a.h = p->h;
     a.N = p->d.N;
-    a.con_stride = p->ncon_nodes();
-    a.node_begin = 0;
-    a.node_end = p->ncon_nodes();
+    a.con_stride = rg.con_stride;
+    a.node_begin = rg.begin;
+    a.node_end = rg.end;
     size_t size = sizeof a;
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a,
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
@@ -218,7 +247,7 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
     } else if (wgs_per_block > 0) {
         // node blocks padded to a multiple of the 8 XCDs (see the kernels'
         // prologue: block -> XCD placement); surplus workgroups exit at once
-        const long long nblk = ((p->ncon_nodes() + 63)/64 + 7)/8*8;
+        const long long nblk = ((rg.end - rg.begin + 63)/64 + 7)/8*8;
         grid = (unsigned)(nblk*wgs_per_block);
         if (grid == 0) return 0;
     }
@@ -229,30 +258,60 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
 
 // what: OPTY_HIP_EVAL_*; device pointers only
 int eval_device(opty_hip_problem *p, int what, const double *free_,
-                double *con, double *jac) {
+                double *con, double *jac, const NodeRange &rg) {
     const int S = p->d.jac_wgs_per_block, T = 64*p->d.jac_waves_per_wg;
+    if (int rc = order_streams(p)) return rc;
     // Node-invariant sub-expressions: recomputed only when their inputs can
     // have changed (always, if they read unknown parameters / h from `free`).
     if (p->d.num_uniform > 0 && (p->uni_dirty || p->d.uniform_dynamic)) {
         if (int rc = launch(p, p->k_uni, -OPTY_UNI_WORKGROUPS, 64, free_, nullptr,
-                                nullptr)) return rc;
+                                nullptr, rg)) return rc;
         p->uni_dirty = false;
     }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block,
-                            64*p->d.con_waves_per_wg, free_, con, nullptr))
+                            64*p->d.con_waves_per_wg, free_, con, nullptr, rg))
             return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac)) return rc;
+        if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac, rg))
+            return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
         if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
-                            64*p->d.fused_waves_per_wg, free_, con, jac))
+                            64*p->d.fused_waves_per_wg, free_, con, jac, rg))
             return rc;
     if (p->d.num_inst > 0) {
+        // only whole-problem evaluations reach this (shards reject instance
+        // constraints): the tails follow the last node's values
         double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr : con;
         double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr : jac;
-        if (int rc = launch(p, p->k_inst, 0, 64, free_, c, j)) return rc;
+        if (int rc = launch(p, p->k_inst, 0, 64, free_, c, j, rg)) return rc;
     }
+    return 0;
+}
+
+int check_shard(const opty_hip_problem *p, int what, const double *free_,
+                const double *con, const double *jac, int64_t con_stride,
+                int64_t node_begin, int64_t node_end) {
+    if (!p) return fail("null handle");
+    if (what != OPTY_HIP_EVAL_CON && what != OPTY_HIP_EVAL_JAC &&
+        what != OPTY_HIP_EVAL_PAIR && what != OPTY_HIP_EVAL_FUSED)
+        return fail("bad evaluation selector %d", what);
+    if (p->d.num_inst > 0)
+        return fail("instance constraints are not node-sharded");
+    if (p->d.layout != OPTY_HIP_LAYOUT_COO)
+        return fail("the CSR layout is not node-sharded");
+    if (node_begin < 0 || node_end < node_begin ||
+        node_end > p->ncon_nodes())
+        return fail("shard [%lld, %lld) outside the %lld constraint nodes",
+                    (long long)node_begin, (long long)node_end,
+                    (long long)p->ncon_nodes());
+    const bool want_con = what != OPTY_HIP_EVAL_JAC;
+    const bool want_jac = what != OPTY_HIP_EVAL_CON;
+    if (!free_ || (want_con && !con) || (want_jac && !jac))
+        return fail("null buffer");
+    if (want_con && con_stride < node_end - node_begin)
+        return fail("con_stride %lld is smaller than the shard's %lld nodes",
+                    (long long)con_stride, (long long)(node_end - node_begin));
     return 0;
 }
 
@@ -273,7 +332,7 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
     if (!free_ || (want_con && !con) || (want_jac && !jac))
         return fail("null buffer");
     if (mem == OPTY_HIP_DEVICE)
-        return eval_device(p, what, free_, con, jac);
+        return eval_device(p, what, free_, con, jac, whole(p));
     if (mem != OPTY_HIP_HOST) return fail("bad memory kind %d", mem);
     // Host buffers (the cyipopt callback case): stage through device memory.
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
@@ -281,9 +340,11 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
         if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
     if (want_jac)
         if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
+    if (int rc = order_streams(p)) return rc;
     HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
                            hipMemcpyHostToDevice, p->stream));
-    if (int rc = eval_device(p, what, p->d_free, p->d_con, p->d_jac))
+    if (int rc = eval_device(p, what, p->d_free, p->d_con, p->d_jac,
+                             whole(p)))
         return rc;
     if (want_con)
         HIP_TRY(hipMemcpyAsync(con, p->d_con, p->num_con()*sizeof(double),
@@ -509,6 +570,7 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
         p->stream = p->own_stream;
         HIP_TRY(hipEventCreate(&p->ev0));
         HIP_TRY(hipEventCreate(&p->ev1));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_order, hipEventDisableTiming));
         if (desc->p_known > 0)
             HIP_TRY(hipMalloc((void **)&p->d_params,
                               desc->p_known*sizeof(double)));
@@ -539,6 +601,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev_order) (void)hipEventDestroy(p->ev_order);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
@@ -685,20 +748,24 @@ int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free_,
     return eval_any(p, OPTY_HIP_EVAL_FUSED, free_, con, jac, mem);
 }
 
+// Indices of the constraint nodes [node_offset, node_offset + count) of a
+// problem with N_global time nodes; `with_inst`: followed by the instance
+// part (whole-problem calls only).
 static int indices_impl(opty_hip_problem *p, int64_t N_global,
-                        int64_t node_offset, int64_t *rows, int64_t *cols,
-                        int32_t mem) {
+                        int64_t node_offset, int64_t count, bool with_inst,
+                        int64_t *rows, int64_t *cols, int32_t mem) {
     if (!rows || !cols) return fail("null buffer");
     if (int rc = use_device(p)) return rc;
     if (p->d.num_inst > 0 && !p->have_inst)
         return fail("instance indices were never set");
-    if (node_offset < 0 || node_offset + p->ncon_nodes() > N_global - 1)
+    if (node_offset < 0 || count < 0 || node_offset + count > N_global - 1)
         return fail("shard [%lld, %lld) outside the %lld constraint nodes",
-                    (long long)node_offset,
-                    (long long)(node_offset + p->ncon_nodes()),
+                    (long long)node_offset, (long long)(node_offset + count),
                     (long long)(N_global - 1));
     long long *dr = (long long *)rows, *dc = (long long *)cols;
-    const size_t nnz = (size_t)p->nnz();
+    const int nnz_inst = with_inst ? p->d.nnz_inst : 0;
+    const size_t nnz = (size_t)(p->P()*count + nnz_inst);
+    if (nnz == 0) return 0;
     if (mem == OPTY_HIP_HOST) {
         if (int rc = ensure(&p->d_rows, nnz)) return rc;
         if (int rc = ensure(&p->d_cols, nnz)) return rc;
@@ -711,7 +778,7 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     d.N = N_global;
     d.ncon = N_global - 1;
     d.offset = node_offset;
-    d.count = p->ncon_nodes();
+    d.count = count;
     d.n = p->d.n;
     d.q = p->d.q;
     d.M = p->d.M;
@@ -724,7 +791,8 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     if (p->d.layout == OPTY_HIP_LAYOUT_CSR && !p->d_rowinfo)
         return fail("the CSR block pattern was never set "
                     "(opty_hip_set_block_pattern)");
-    if (p->d.layout == OPTY_HIP_LAYOUT_CSR && node_offset != 0)
+    if (p->d.layout == OPTY_HIP_LAYOUT_CSR &&
+        (node_offset != 0 || count != N_global - 1))
         return fail("the CSR layout is not node-sharded");
     if (p->d.P != p->d.M*p->d.C && !p->d_pattern)
         return fail("the block pattern was never set "
@@ -734,11 +802,13 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     int npb = P >= 1024 ? 1 : (1024 + P - 1)/P;
     const unsigned grid = (unsigned)((d.count + npb - 1)/npb);
     (void)hipGetLastError();    // drop whatever an earlier failed call left
-    hipLaunchKernelGGL(opty_indices_kernel, dim3(grid), dim3(256), 0,
-                       p->stream, d, dr, dc, npb);
-    HIP_TRY(hipGetLastError());
-    const size_t base = (size_t)(p->P()*p->ncon_nodes());
-    if (p->d.nnz_inst > 0) {
+    if (grid > 0) {
+        hipLaunchKernelGGL(opty_indices_kernel, dim3(grid), dim3(256), 0,
+                           p->stream, d, dr, dc, npb);
+        HIP_TRY(hipGetLastError());
+    }
+    const size_t base = (size_t)(p->P()*count);
+    if (nnz_inst > 0) {
         HIP_TRY(hipMemcpyAsync(dr + base, p->d_inst_rows,
                                p->d.nnz_inst*sizeof(int64_t),
                                hipMemcpyDeviceToDevice, p->stream));
@@ -763,7 +833,16 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
 int opty_hip_jacobian_indices(opty_hip_problem *p, int64_t *rows,
                               int64_t *cols, int32_t mem) {
     if (!p) return fail("null handle");
-    return indices_impl(p, p->d.N, 0, rows, cols, mem);
+    return indices_impl(p, p->d.N, 0, p->ncon_nodes(), true, rows, cols, mem);
+}
+
+int opty_hip_jacobian_indices_range(opty_hip_problem *p, int64_t node_begin,
+                                    int64_t node_end, int64_t *rows,
+                                    int64_t *cols, int32_t mem) {
+    if (!p) return fail("null handle");
+    if (node_end < node_begin) return fail("empty node range");
+    return indices_impl(p, p->d.N, node_begin, node_end - node_begin, false,
+                        rows, cols, mem);
 }
 
 int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
@@ -772,30 +851,77 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
     if (!p) return fail("null handle");
     if (p->d.num_inst > 0)
         return fail("instance constraints are not node-sharded");
-    return indices_impl(p, N_global, node_offset, rows, cols, mem);
+    if (p->d.layout == OPTY_HIP_LAYOUT_CSR)
+        return fail("the CSR layout is not node-sharded");
+    return indices_impl(p, N_global, node_offset, p->ncon_nodes(), false,
+                        rows, cols, mem);
 }
 
-int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
-                       double *con, double *jac, int32_t iters,
-                       float *ms_per_iter) {
-    if (!p || !ms_per_iter) return fail("null argument");
+static int time_impl(opty_hip_problem *p, int32_t what, const double *free_,
+                     double *con, double *jac, const NodeRange &rg,
+                     int32_t iters, float *ms_per_iter) {
+    if (!ms_per_iter) return fail("null argument");
     if (iters < 1) return fail("iters must be >= 1");
     if (int rc = use_device(p)) return rc;
     if (int rc = check_ready(p)) return rc;
+    if (int rc = order_streams(p)) return rc;
     if (p->d.num_uniform > 0 && p->uni_dirty && !p->d.uniform_dynamic) {
         // keep the one-off table fill out of the timed region
         if (int rc = launch(p, p->k_uni, -OPTY_UNI_WORKGROUPS, 64, free_, nullptr,
-                                nullptr)) return rc;
+                                nullptr, rg)) return rc;
         p->uni_dirty = false;
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     for (int it = 0; it < iters; ++it)
-        if (int rc = eval_device(p, what, free_, con, jac)) return rc;
+        if (int rc = eval_device(p, what, free_, con, jac, rg)) return rc;
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     HIP_TRY(hipEventSynchronize(p->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, p->ev0, p->ev1));
     *ms_per_iter = ms/iters;
+    return 0;
+}
+
+int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
+                       double *con, double *jac, int32_t iters,
+                       float *ms_per_iter) {
+    if (!p) return fail("null argument");
+    return time_impl(p, what, free_, con, jac, whole(p), iters, ms_per_iter);
+}
+
+int opty_hip_eval_shard(opty_hip_problem *p, int32_t what, const double *free_,
+                        double *con, int64_t con_stride, double *jac,
+                        int64_t node_begin, int64_t node_end) {
+    if (int rc = check_shard(p, what, free_, con, jac, con_stride, node_begin,
+                             node_end)) return rc;
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    if (node_end == node_begin) return 0;
+    return eval_device(p, what, free_, con, jac,
+                       NodeRange{node_begin, node_end, con_stride});
+}
+
+int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
+                             const double *free_, double *con,
+                             int64_t con_stride, double *jac,
+                             int64_t node_begin, int64_t node_end,
+                             int32_t iters, float *ms_per_iter) {
+    if (int rc = check_shard(p, what, free_, con, jac, con_stride, node_begin,
+                             node_end)) return rc;
+    return time_impl(p, what, free_, con, jac,
+                     NodeRange{node_begin, node_end, con_stride}, iters,
+                     ms_per_iter);
+}
+
+int opty_hip_host_register(void *ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return fail("null argument");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    return 0;
+}
+
+int opty_hip_host_unregister(void *ptr) {
+    if (!ptr) return 0;
+    HIP_TRY(hipHostUnregister(ptr));
     return 0;
 }
 

@@ -46,7 +46,9 @@ class ConstraintCollocator(object):
       ``'cython'`` / ``'numpy'`` do not exist here;
     * ``parallel`` is accepted and ignored (a GPU launch is always parallel);
     * ``tmp_dir`` is the code-object cache directory;
-    * extra keywords ``device`` (HIP ordinal), ``emit_options`` and
+    * extra keywords ``device`` (HIP ordinal), ``emit_options``,
+      ``launch_nodes`` (constraint nodes per launch when the handle evaluates
+      node shards, :mod:`opty_amd.sharded`) and
       ``jacobian_layout='csr'``: opt-in, stores the Jacobian values sorted by
       row then column (see ``jacobian_csr_structure``);
       ``prune_zeros``: opt-in, drops the structurally zero entries of the
@@ -66,8 +68,11 @@ class ConstraintCollocator(object):
                  integration_method='backward euler', parallel=False,
                  show_compile_output=False, backend='hip', device=0,
                  emit_options=None, prune_zeros=False,
-                 jacobian_layout='coo'):
+                 jacobian_layout='coo', launch_nodes=None):
         self._prune_zeros = bool(prune_zeros)
+        # constraint nodes one launch covers (a node shard evaluates fewer
+        # than N - 1): picks the kernels' strip count for small launches
+        self._launch_nodes = launch_nodes
         if jacobian_layout not in ('coo', 'csr'):
             raise ValueError('jacobian_layout must be "coo" or "csr".')
         self._jacobian_layout = jacobian_layout
@@ -518,7 +523,9 @@ class ConstraintCollocator(object):
 
     def generate_source(self):
         """HIP source of this problem's kernels and its launch metadata."""
-        return emit_module(self._build_program(), self._emit_options)
+        nodes = self._launch_nodes or self.num_collocation_nodes - 1
+        return emit_module(self._build_program(), self._emit_options,
+                           node_blocks=(int(nodes) + 63)//64)
 
     def _descriptor(self, meta):
         prog = self._program
@@ -561,14 +568,12 @@ class ConstraintCollocator(object):
         hsaco = hb.compile_module(source, self.tmp_dir,
                                   self.show_compile_output)
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
-        hip.set_known_parameters([float(self.known_parameter_map[p])
-                                  for p in self.known_parameters])
         if not self._variable_duration:
             hip.set_interval(self.node_time_interval)
         self._callable_known = any(
             callable(v) for v in self.known_trajectory_map.values())
-        if self.num_known_input_trajectories and not self._callable_known:
-            hip.set_known_trajectories(self._known_trajectory_array(None))
+        self._uploaded_parameters = self._uploaded_trajectories = None
+        self._sync_known(hip, None)
         if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
         if self.num_instance_constraints:
@@ -585,12 +590,45 @@ class ConstraintCollocator(object):
         evaluation, timing)."""
         return self._ensure_hip()
 
-    def _refresh_callable_known(self, hip, free):
-        # known trajectories given as functions of ``free``
-        # (opty/direct_collocation.py:2916-2917) are re-evaluated on the host
-        # and re-uploaded on every call.
-        if self.num_known_input_trajectories and self._callable_known:
-            hip.set_known_trajectories(self._known_trajectory_array(free))
+    def _sync_known(self, hip, free):
+        """Brings the device copies of the known parameters and trajectories
+        up to date with ``known_parameter_map`` / ``known_trajectory_map``.
+
+        The reference reads both maps on every call (``_merge_fixed_free``,
+        ``opty/direct_collocation.py:2891-2926``), so a user may change a
+        value between solves (``plot_human_gait.py`` does:
+        ``prob.collocator.known_parameter_map[g] = ...``).  Here the maps are
+        re-read on every call too, compared with what the device holds and
+        re-uploaded only when they differ.  Known trajectories given as
+        functions of ``free`` (``:2916-2917``) are re-evaluated on the host
+        every call; ``free`` is None at setup, when those are skipped."""
+        if self.num_known_parameters:
+            vals = np.array([float(self.known_parameter_map[p])
+                             for p in self.known_parameters])
+            if (self._uploaded_parameters is None or
+                    not np.array_equal(vals, self._uploaded_parameters)):
+                hip.set_known_parameters(vals)
+                self._uploaded_parameters = vals
+        if self.num_known_input_trajectories:
+            if self._callable_known and free is None:
+                return
+            vals = self._known_trajectory_array(free)
+            if vals.shape != (self.num_known_input_trajectories,
+                              self.num_collocation_nodes):
+                raise ValueError('every known trajectory must have {} '
+                                 'values.'.format(self.num_collocation_nodes))
+            if (self._uploaded_trajectories is None or
+                    not np.array_equal(vals, self._uploaded_trajectories)):
+                hip.set_known_trajectories(vals)
+                # np.array above copied: later in-place edits of the user's
+                # arrays are seen as a difference
+                self._uploaded_trajectories = vals
+
+    def sync_known(self):
+        """Uploads changed ``known_parameter_map`` / ``known_trajectory_map``
+        values now; for callers that evaluate through :attr:`hip` with device
+        pointers (the host callbacks do this on every call)."""
+        self._sync_known(self._ensure_hip(), None)
 
     def _host_free(self, free):
         free = np.ascontiguousarray(free, dtype=np.float64)
@@ -610,7 +648,7 @@ class ConstraintCollocator(object):
 
         def constraints(free):
             free = self._host_free(free)
-            self._refresh_callable_known(hip, free)
+            self._sync_known(hip, free)
             out = np.empty(self.num_constraints)      # fresh, as :2444
             hip.eval_con(free, out, hb.HOST)
             return out
@@ -628,7 +666,7 @@ class ConstraintCollocator(object):
 
         def jacobian(free):
             free = self._host_free(free)
-            self._refresh_callable_known(hip, free)
+            self._sync_known(hip, free)
             hip.eval_jac(free, result, hb.HOST)
             return result
         return jacobian

@@ -158,9 +158,19 @@ _SIGNATURES = {
                                                  ctypes.c_int32]),
     'opty_hip_jacobian_indices_shard': (ctypes.c_int, [
         _P, ctypes.c_int64, ctypes.c_int64, _P, _P, ctypes.c_int32]),
+    'opty_hip_jacobian_indices_range': (ctypes.c_int, [
+        _P, ctypes.c_int64, ctypes.c_int64, _P, _P, ctypes.c_int32]),
     'opty_hip_time_eval': (ctypes.c_int, [_P, ctypes.c_int32, _P, _P, _P,
                                           ctypes.c_int32,
                                           ctypes.POINTER(ctypes.c_float)]),
+    'opty_hip_eval_shard': (ctypes.c_int, [
+        _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
+        ctypes.c_int64]),
+    'opty_hip_time_eval_shard': (ctypes.c_int, [
+        _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
+        ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
+    'opty_hip_host_register': (ctypes.c_int, [_P, ctypes.c_size_t]),
+    'opty_hip_host_unregister': (ctypes.c_int, [_P]),
     'opty_hip_objective_create': (ctypes.c_int, [ctypes.POINTER(_ObjDesc),
                                                  ctypes.c_char_p,
                                                  ctypes.POINTER(_P)]),
@@ -254,6 +264,17 @@ def pinned_empty(count, dtype=np.float64):
 _PINNED_OWNERS = {}
 
 
+def host_register(array):
+    """Page-locks the memory of a NumPy array the caller owns (e.g. a
+    shared-memory mapping); pair with :func:`host_unregister`."""
+    _check(load_library().opty_hip_host_register(array.ctypes.data,
+                                                 array.nbytes))
+
+
+def host_unregister(array):
+    _check(load_library().opty_hip_host_unregister(array.ctypes.data))
+
+
 class HipProblem(object):
     """One ``opty_hip_problem`` handle."""
 
@@ -338,6 +359,26 @@ class HipProblem(object):
         _check(self._lib.opty_hip_jacobian_indices_shard(
             self._h, num_nodes_global, node_offset, _ptr(rows), _ptr(cols),
             mem))
+
+    def jacobian_indices_range(self, node_begin, node_end, rows, cols, mem):
+        _check(self._lib.opty_hip_jacobian_indices_range(
+            self._h, node_begin, node_end, _ptr(rows), _ptr(cols), mem))
+
+    def eval_shard(self, what, free, con, con_stride, jac, node_begin,
+                   node_end):
+        """Constraint nodes ``[node_begin, node_end)`` from the global device
+        ``free``; see ``opty_hip_eval_shard`` in ``include/opty_hip.h``."""
+        _check(self._lib.opty_hip_eval_shard(
+            self._h, what, _ptr(free), _ptr(con), con_stride, _ptr(jac),
+            node_begin, node_end))
+
+    def time_eval_shard(self, what, free, con, con_stride, jac, node_begin,
+                        node_end, iters):
+        ms = ctypes.c_float()
+        _check(self._lib.opty_hip_time_eval_shard(
+            self._h, what, _ptr(free), _ptr(con), con_stride, _ptr(jac),
+            node_begin, node_end, iters, ctypes.byref(ms)))
+        return ms.value
 
     def time_eval(self, what, free, con, jac, iters):
         ms = ctypes.c_float()

@@ -1,29 +1,44 @@
-"""Node sharding of one collocation problem over the GPUs of a node
-(one process per GPU, ``torch.distributed``; backend ``nccl`` = RCCL over xGMI
-on GPUs, ``gloo`` in the CPU tests).
+"""Node sharding of ONE collocation problem over the GPUs of a node
+(BASELINE config 4; one process per GPU, ``torch.distributed``: backend
+``nccl`` = RCCL over xGMI on GPUs, ``gloo`` in the CPU tests).
 
 The path shards naturally: constraint node ``i`` reads only
 time nodes ``i`` and ``i + 1`` of every trajectory row
-(``opty/direct_collocation.py:2145, 2153-2155, 2411-2413``), so rank ``g``
-with constraint nodes ``[a_g, b_g)`` needs the time-node columns
-``[a_g, b_g]`` -- a one-node halo -- plus the node-invariant tail of ``free``.
-That slab *is* the free vector of an ordinary collocation problem with
-``b_g - a_g + 1`` nodes, so every rank simply runs an unmodified
-:class:`opty_amd.ConstraintCollocator` on its slab:
+(``opty/direct_collocation.py:2145, 2153-2155, 2411-2413``).  Rank ``g`` owns
+the constraint nodes ``[a_g, b_g)`` and
 
-* the Jacobian shard is the contiguous slice ``[a_g*P, b_g*P)`` of the global
-  node-major value vector;
-* the constraint shard is, per equation ``j``, the slice
-  ``[j*(N-1) + a_g, j*(N-1) + b_g)`` of the global equation-major vector;
+* evaluates them with ``opty_hip_eval_shard`` straight from the GLOBAL free
+  vector in its HBM -- no host slicing, the kernels take the node range as an
+  argument and read the time-node columns ``[a_g, b_g]`` (one-node halo);
+* its Jacobian shard is the contiguous slice ``[a_g*P, b_g*P)`` of the global
+  node-major value vector (``:2885-2887``);
+* its constraint shard is, per equation ``j``, the segment
+  ``[j*(N-1) + a_g, j*(N-1) + b_g)`` of the global equation-major vector
+  (``:2446``);
 * the COO indices need no communication (closed form with the global ``N``).
 
-No collective is needed to *evaluate*.  Re-assembling the full vectors (what a
-single-process IPOPT wants) is one all-gather per output.
+Evaluation needs **no collective**.  What a single-process IPOPT wants -- the
+whole vectors in one place -- is offered three ways, never folded into the
+evaluation itself:
+
+``gather(dst)``     point-to-point gather-v over RCCL: every rank sends its two
+                    shards, ``dst`` receives the Jacobian slices *in place*
+                    (views of the global vector, shard sizes may differ) and
+                    the constraint blocks into a staging buffer that one
+                    strided device copy scatters to ``j*(N-1) + a_g``;
+``all_gather()``    the same exchange with every rank as a destination;
+``to_host(vec)``    every rank copies its shard over its *own* PCIe link into
+                    one page-locked host vector shared by all processes
+                    (:class:`SharedHostVector`) -- 8 links in parallel instead
+                    of funnelling 792 MB through one GPU.
 """
+
+import os
 
 import numpy as np
 
-__all__ = ['partition_nodes', 'ShardedCollocator']
+__all__ = ['partition_nodes', 'slab_of', 'ShardedCollocator',
+           'SharedHostVector']
 
 
 def partition_nodes(num_constraint_nodes, world_size):
@@ -38,29 +53,102 @@ def partition_nodes(num_constraint_nodes, world_size):
     return out
 
 
+def slab_of(free_global, num_nodes, num_rows, a, b):
+    """The free vector of the ``(b - a + 1)``-node problem that constraint
+    nodes ``[a, b)`` of an ``num_nodes``-node problem form: columns
+    ``[a, b]`` of each of the ``num_rows`` trajectory rows (states, then
+    unknown inputs) followed by the node-invariant tail.  Host helper (tests,
+    callers that keep ``free`` on the host); the device path never builds
+    it."""
+    free_global = np.asarray(free_global)
+    rows = free_global[:num_rows*num_nodes].reshape(num_rows, num_nodes)
+    return np.concatenate((rows[:, a:b + 1].ravel(),
+                           free_global[num_rows*num_nodes:]))
+
+
+class SharedHostVector(object):
+    """One float64 host vector mapped by every rank of the node (a file in
+    ``/dev/shm``), page-locked in each process so that device-to-host copies
+    into it run at PCIe rate.  Rank ``owner`` creates it; it is what the
+    process that runs IPOPT reads.
+
+    ``torch_view(lo, hi)`` is a CPU tensor over ``[lo, hi)`` for
+    ``copy_(device_tensor, non_blocking=True)``.
+    """
+
+    def __init__(self, name, count, rank, group=None, owner=0, pin=True):
+        import torch.distributed as dist
+        self.path = os.path.join('/dev/shm', name)
+        self.count = int(count)
+        self._pinned = False
+        multi = dist.is_available() and dist.is_initialized()
+        if rank == owner:
+            self.array = np.memmap(self.path, dtype=np.float64, mode='w+',
+                                   shape=(self.count,))
+        if multi:
+            dist.barrier(group)
+        if rank != owner:
+            self.array = np.memmap(self.path, dtype=np.float64, mode='r+',
+                                   shape=(self.count,))
+        if multi:
+            dist.barrier(group)
+        if rank == owner:
+            os.unlink(self.path)        # the mappings keep the memory alive
+        if pin:
+            from . import hip_backend as hb
+            hb.host_register(self.array)
+            self._pinned = True
+
+    def torch_view(self, lo=0, hi=None):
+        import torch
+        return torch.from_numpy(self.array[lo:self.count if hi is None
+                                           else hi])
+
+    def close(self):
+        if self._pinned:
+            from . import hip_backend as hb
+            hb.host_unregister(self.array)
+            self._pinned = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedCollocator(object):
-    """One rank's view of a node-sharded collocation problem.
+    """One rank's share of a node-sharded collocation problem.
 
     Parameters are those of :class:`opty_amd.ConstraintCollocator` for the
     GLOBAL problem, plus ``rank`` / ``world_size`` (default: from
-    ``torch.distributed``), and ``local_factory`` -- a callable that builds the
-    local evaluator from the local keyword dict (default: the HIP
-    ``ConstraintCollocator``; the CPU tests inject the oracle).  The local
-    evaluator must offer ``generate_constraint_function()``,
-    ``generate_jacobian_function()``, ``num_free``, ``num_states`` and
-    ``num_unknown_input_trajectories``.
+    ``torch.distributed``), ``group`` and ``device`` (a ``torch.device``;
+    default: the collocator's HIP device).
 
-    Instance constraints are not node-sharded; they stay with the caller.
+    ``evaluator``: ``f(free, con2d, jac1d, a, b)`` that fills the shard's
+    ``(M, b - a)`` constraint block (a possibly strided view) and its
+    ``(b - a)*P`` Jacobian values from the global ``free`` tensor.  Default:
+    the HIP kernels (``opty_hip_eval_shard``); the CPU tests inject an
+    oracle-backed one to exercise the partition and the exchange under
+    ``gloo``.  With an evaluator, ``block_shape = (M, P)`` must be given.
+
+    Instance constraints and the CSR layout are not node-sharded.
     """
 
     def __init__(self, equations_of_motion, state_symbols,
                  num_collocation_nodes, node_time_interval,
                  known_parameter_map={}, known_trajectory_map={},
                  instance_constraints=None, rank=None, world_size=None,
-                 group=None, local_factory=None, **kwargs):
+                 group=None, device=None, evaluator=None, block_shape=None,
+                 **kwargs):
+        import torch
         if instance_constraints is not None:
             raise NotImplementedError('instance constraints are evaluated by '
                                       'the caller, not by the node shards')
+        if kwargs.get('jacobian_layout', 'coo') != 'coo':
+            raise NotImplementedError(
+                'the row-sorted (csr) layout is not node-sharded: a shard of '
+                'it is not a contiguous slice of the global value vector')
         if rank is None or world_size is None:
             import torch.distributed as dist
             rank = dist.get_rank(group)
@@ -75,22 +163,37 @@ class ShardedCollocator(object):
             if callable(v):
                 raise NotImplementedError('callable known trajectories are '
                                           'not supported by the node shards')
-            if len(v) != self.N:
-                raise ValueError('The known parameter {} is not length {}.'
-                                 .format(k, self.N))
-        local_known = {k: np.ascontiguousarray(v[self.a:self.b + 1])
-                       for k, v in known_trajectory_map.items()}
-        local_kw = dict(equations_of_motion=equations_of_motion,
-                        state_symbols=state_symbols,
-                        num_collocation_nodes=self.b - self.a + 1,
-                        node_time_interval=node_time_interval,
-                        known_parameter_map=known_parameter_map,
-                        known_trajectory_map=local_known, **kwargs)
-        if local_factory is None:
+        self.collocator = None
+        if evaluator is None:
             from .direct_collocation import ConstraintCollocator
-            local_factory = lambda kw: ConstraintCollocator(**kw)
-        self.local = local_factory(local_kw)
-        self._con = self._jac = None
+            if device is not None:
+                kwargs.setdefault('device', torch.device(device).index or 0)
+            # the handle is built for the GLOBAL problem (its kernels read
+            # the global free vector); its strip count is chosen for the
+            # shard's launch size
+            self.collocator = ConstraintCollocator(
+                equations_of_motion, state_symbols, num_collocation_nodes,
+                node_time_interval, known_parameter_map, known_trajectory_map,
+                launch_nodes=max(b - a for a, b in self.ranges), **kwargs)
+            prog = self.collocator._build_program()
+            self.M, self.P = prog.M, prog.P
+            self.device = torch.device('cuda', self.collocator._device)
+            evaluator = self._hip_evaluate
+        else:
+            if block_shape is None:
+                raise ValueError('block_shape=(M, P) is needed with an '
+                                 'evaluator')
+            self.M, self.P = block_shape
+            self.device = torch.device(device or 'cpu')
+        self._evaluate = evaluator
+        cnt = self.b - self.a
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.con_local = torch.empty((self.M, cnt), **f64)
+        self.jac_local = torch.empty(cnt*self.P, **f64)
+        self._global = None         # (con, jac) on ranks that receive
+        self._stage = None          # constraint blocks of the other ranks
+        self._in_place = False
+        self._stream = None
 
     # -- layout ---------------------------------------------------------------
     @property
@@ -98,81 +201,183 @@ class ShardedCollocator(object):
         """Constraint nodes owned by this rank."""
         return self.b - self.a
 
-    def local_free(self, free_global, num_rows, num_tail):
-        """The rank's slab of the global free vector: columns ``[a, b]`` of
-        each of the ``num_rows`` trajectory rows (states, then unknown
-        inputs), followed by the ``num_tail`` node-invariant entries."""
-        free_global = np.asarray(free_global)
-        N = self.N
-        rows = free_global[:num_rows*N].reshape(num_rows, N)
-        tail = free_global[num_rows*N:]
-        assert len(tail) == num_tail
-        return np.concatenate((rows[:, self.a:self.b + 1].ravel(), tail))
+    def _global_buffers(self):
+        import torch
+        if self._global is None:
+            f64 = dict(dtype=torch.float64, device=self.device)
+            ncn = self.N - 1
+            self._global = (torch.empty(self.M*ncn, **f64),
+                            torch.empty(self.P*ncn, **f64))
+            self._stage = {
+                g: torch.empty((self.M, b - a), **f64)
+                for g, (a, b) in enumerate(self.ranges) if g != self.rank}
+        return self._global
 
-    def _rows_tail(self):
-        loc = self.local
-        num_rows = loc.num_states + loc.num_unknown_input_trajectories
-        return num_rows, loc.num_free - num_rows*(self.b - self.a + 1)
+    def _own_views(self):
+        """This rank's shard as views of the global vectors."""
+        con, jac = self._global_buffers()
+        return (con.view(self.M, self.N - 1)[:, self.a:self.b],
+                jac[self.a*self.P:self.b*self.P])
 
-    # -- evaluation -------------------------------------------------------------
+    # -- evaluation (no collective) ----------------------------------------------
+    def _hip_evaluate(self, free, con2d, jac1d, a, b):
+        import torch
+        from . import hip_backend as hb
+        # the kernels run on torch's current stream, so that the exchange and
+        # the copies that follow (torch / RCCL ops) are ordered behind them
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if stream != self._stream:
+            self.collocator.hip.set_stream(stream)
+            self._stream = stream
+        self.collocator.hip.eval_shard(
+            hb.EVAL_FUSED, free, con2d, con2d.stride(0), jac1d, a, b)
+
+    def evaluate(self, free, in_place=False):
+        """Constraints and Jacobian of this rank's nodes from the global
+        ``free`` tensor (on this rank's device).  Returns ``(con, jac)``:
+        ``con`` is ``(M, b - a)`` (row ``j`` = equation ``j``), ``jac`` the
+        slice ``[a*P, b*P)`` of the global value vector.  ``in_place``: write
+        the shard directly into this rank's copy of the global vectors (what
+        a gather destination does, so that its own share is never copied)."""
+        if free.numel() != self._num_free():
+            raise ValueError('free must have {} entries, got {}'.format(
+                self._num_free(), free.numel()))
+        con, jac = self._own_views() if in_place else \
+            (self.con_local, self.jac_local)
+        self._evaluate(free, con, jac, self.a, self.b)
+        self._in_place = bool(in_place)
+        return con, jac
+
+    def _num_free(self):
+        if self.collocator is not None:
+            return self.collocator.num_free
+        return self._free_size
+
+    def set_num_free(self, count):
+        """Length of the global free vector (injected evaluators only)."""
+        self._free_size = int(count)
+
+    def broadcast_free(self, free, src=0):
+        """RCCL broadcast of the global free vector from rank ``src`` (18 MB
+        for config 4).  The alternative with ``free`` on the host: every rank
+        loads it over its own PCIe link from a :class:`SharedHostVector`."""
+        import torch.distributed as dist
+        dist.broadcast(free, src, group=self.group)
+        return free
+
+    # -- re-assembly (the only communication) ---------------------------------------
+    def _exchange(self, dsts):
+        """Every rank sends its two shards to every rank in ``dsts`` (but
+        itself); destinations receive the Jacobian slices in place and the
+        constraint blocks into staging.  One batch of point-to-point ops:
+        shard sizes differ by up to one node, which an all-gather of equal
+        pieces cannot express without padding copies."""
+        import torch.distributed as dist
+        recvs, sends = [], []               # (device tensor, peer)
+        if self.rank in dsts:
+            con_g, jac_g = self._global_buffers()
+            if not self._in_place:
+                own_con, own_jac = self._own_views()
+                own_con.copy_(self.con_local)
+                own_jac.copy_(self.jac_local)
+            for g, (a, b) in enumerate(self.ranges):
+                if g != self.rank:
+                    recvs.append((jac_g[a*self.P:b*self.P], g))
+                    recvs.append((self._stage[g], g))
+        src_con, src_jac = (self._own_views() if self._in_place
+                            else (self.con_local, self.jac_local))
+        if self._in_place and any(d != self.rank for d in dsts):
+            # the constraint shard inside the global vector is strided
+            self.con_local.copy_(src_con)
+            src_con = self.con_local
+        for d in dsts:
+            if d != self.rank:
+                sends += [(src_jac, d), (src_con, d)]
+        # gloo moves host memory only: a GPU run that rendezvoused with gloo
+        # (several ranks sharing one GPU on a development box -- RCCL refuses
+        # duplicate devices) stages the messages through the host
+        via_host = (self.device.type == 'cuda' and
+                    dist.get_backend(self.group) == 'gloo')
+        landing = [(t.cpu() if via_host else t) for t, _ in recvs]
+        ops = [dist.P2POp(dist.irecv, buf, g, self.group)
+               for buf, (_, g) in zip(landing, recvs)]
+        ops += [dist.P2POp(dist.isend, t.cpu() if via_host else t, d,
+                           self.group) for t, d in sends]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if via_host:
+            for buf, (t, _) in zip(landing, recvs):
+                t.copy_(buf)
+        if self.rank in dsts:
+            con2d = con_g.view(self.M, self.N - 1)
+            for g, (a, b) in enumerate(self.ranges):
+                if g != self.rank:
+                    con2d[:, a:b].copy_(self._stage[g])
+            return con_g, jac_g
+        return None
+
+    def gather(self, dst=0):
+        """Gather-v of the last :meth:`evaluate` to rank ``dst``: returns the
+        full equation-major constraint vector and node-major Jacobian value
+        vector there (device tensors owned by this object, overwritten by the
+        next call), ``None`` on the other ranks."""
+        return self._exchange([dst])
+
+    def all_gather(self):
+        """The full vectors on every rank."""
+        return self._exchange(list(range(self.world_size)))
+
+    def to_host(self, con_host, jac_host):
+        """Copies this rank's shard into the node-wide host vectors
+        (:class:`SharedHostVector` of ``M*(N-1)`` and ``P*(N-1)`` doubles) over
+        this rank's own PCIe link; asynchronous on the current stream."""
+        con, jac = (self._own_views() if self._in_place
+                    else (self.con_local, self.jac_local))
+        jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
+            jac, non_blocking=True)
+        ncn = self.N - 1
+        dst = con_host.torch_view().view(self.M, ncn)[:, self.a:self.b]
+        if self._in_place:
+            self.con_local.copy_(con)
+            con = self.con_local
+        # M row segments of the equation-major vector
+        dst.copy_(con, non_blocking=True)
+
+    # -- host conveniences (NumPy in, NumPy out on every rank) -----------------------
+    def _as_device(self, free_global):
+        import torch
+        return torch.as_tensor(np.ascontiguousarray(free_global,
+                                                    dtype=np.float64),
+                               device=self.device)
+
     def constraints_local(self, free_global):
         """``(M, b - a)`` equation-major shard of ``constraints(free)``."""
-        if self._con is None:
-            self._con = self.local.generate_constraint_function()
-        num_rows, num_tail = self._rows_tail()
-        con = self._con(self.local_free(free_global, num_rows, num_tail))
-        return np.asarray(con).reshape(-1, self.num_local_nodes)
+        con, _ = self.evaluate(self._as_device(free_global))
+        return con.cpu().numpy()
 
     def jacobian_local(self, free_global):
         """Contiguous slice ``[a*P, b*P)`` of ``jacobian(free)``."""
-        if self._jac is None:
-            self._jac = self.local.generate_jacobian_function()
-        num_rows, num_tail = self._rows_tail()
-        return np.asarray(
-            self._jac(self.local_free(free_global, num_rows, num_tail)))
+        _, jac = self.evaluate(self._as_device(free_global))
+        return jac.cpu().numpy()
 
-    # -- re-assembly (the only collectives) --------------------------------------
-    def _all_gather(self, local, device=None):
-        """All-gather of variable-size 1-D shards (sizes differ by <= one
-        node): pad to the largest shard, one ``all_gather_into_tensor``."""
-        import torch
-        import torch.distributed as dist
-        sizes = [int(np.prod(s)) for s in self._shard_shapes(local)]
-        width = max(sizes)
-        t = torch.zeros(width, dtype=torch.float64, device=device)
-        t[:local.size] = torch.as_tensor(np.ascontiguousarray(local).ravel(),
-                                         device=device)
-        out = torch.empty(self.world_size*width, dtype=torch.float64,
-                          device=device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
-        out = out.cpu().numpy().reshape(self.world_size, width)
-        return [out[g, :sizes[g]] for g in range(self.world_size)]
-
-    def _shard_shapes(self, local):
-        per_node = local.size//self.num_local_nodes
-        return [((b - a)*per_node,) for a, b in self.ranges]
-
-    def constraints(self, free_global, device=None):
+    def constraints(self, free_global):
         """Full equation-major ``constraints(free)`` on every rank."""
-        loc = self.constraints_local(free_global)
-        M = loc.shape[0]
-        parts = self._all_gather(loc, device)
-        blocks = [p.reshape(M, b - a) for p, (a, b) in zip(parts,
-                                                           self.ranges)]
-        return np.hstack(blocks).ravel()
+        self.evaluate(self._as_device(free_global))
+        return self.all_gather()[0].cpu().numpy()
 
-    def jacobian(self, free_global, device=None):
+    def jacobian(self, free_global):
         """Full node-major ``jacobian(free)`` on every rank."""
-        return np.concatenate(self._all_gather(self.jacobian_local(
-            free_global), device))
+        self.evaluate(self._as_device(free_global))
+        return self.all_gather()[1].cpu().numpy()
 
     def jacobian_indices_local(self):
         """Global int64 COO indices of this rank's Jacobian slice, from the
-        device index kernel run with the global ``N`` and this rank's node
-        offset (needs the HIP local evaluator)."""
+        closed-form index kernel restricted to this rank's nodes."""
         from . import hip_backend as hb
-        hip = self.local.hip
-        rows = np.empty(hip.nnz, dtype=np.int64)
-        cols = np.empty(hip.nnz, dtype=np.int64)
-        hip.jacobian_indices_shard(self.N, self.a, rows, cols, hb.HOST)
+        hip = self.collocator.hip
+        count = (self.b - self.a)*self.P
+        rows = np.empty(count, dtype=np.int64)
+        cols = np.empty(count, dtype=np.int64)
+        hip.jacobian_indices_range(self.a, self.b, rows, cols, hb.HOST)
         return rows, cols

@@ -21,3 +21,35 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst per-entry errors the parity checks saw (relative to the entry,
+    and in units of the entry's rounding-error bound), so that drift is
+    visible even while everything passes; also written to
+    ``gpurun_out/parity_stats.json`` on a GPU box."""
+    try:
+        import golden_util as gu
+    except ImportError:
+        return
+    if not gu.STATS:
+        return
+    import json
+    worst = sorted(gu.STATS.items(),
+                   key=lambda kv: -kv[1]['worst_bound_units'])
+    tr = terminalreporter
+    tr.write_line('parity: worst per-entry errors (top 8 of %d labels)'
+                  % len(worst))
+    for label, st in worst[:8]:
+        tr.write_line('  %-44s rel %.2e   %.2f bound units   (%d entries)'
+                      % (label[:44], st['worst_rel'],
+                         st['worst_bound_units'], st['entries']))
+    out = os.path.join(REPO, 'gpurun_out')
+    try:
+        import torch
+        if torch.cuda.is_available():
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, 'parity_stats.json'), 'w') as f:
+                json.dump(gu.STATS, f, indent=1, sort_keys=True)
+    except Exception:
+        pass

@@ -50,6 +50,136 @@ def evaluate(dag, roots, inputs):
     return [val[r] for r in roots]
 
 
+# d f / d x of the unary functions, for the error propagation below
+_DUN = {'sqrt': lambda x, f: 0.5/f, 'sin': lambda x, f: np.cos(x),
+        'cos': lambda x, f: np.sin(x), 'tan': lambda x, f: 1.0 + f*f,
+        'exp': lambda x, f: f, 'log': lambda x, f: 1.0/x,
+        'abs': lambda x, f: 1.0, 'sign': lambda x, f: 0.0,
+        'asin': lambda x, f: 1.0/np.sqrt(1.0 - x*x),
+        'acos': lambda x, f: 1.0/np.sqrt(1.0 - x*x),
+        'atan': lambda x, f: 1.0/(1.0 + x*x), 'sinh': lambda x, f: np.cosh(x),
+        'cosh': lambda x, f: np.sinh(x), 'tanh': lambda x, f: 1.0 - f*f,
+        'step': lambda x, f: 0.0}
+
+
+def evaluate_with_error_bound(dag, roots, inputs):
+    """Values and first-order rounding-error bounds, in units of the float64
+    unit round-off: ``|computed - exact| <~ u * bound`` for ANY evaluation
+    order of the same sums and products (running error analysis: every
+    operation contributes one rounding of its own result plus its operands'
+    errors scaled by the partial derivatives).  An entry that is a sum of
+    large cancelling terms gets a bound at the size of the terms, an entry
+    that is a constant or a single product a bound at its own size -- the
+    per-entry floor of the parity tolerance (``golden_util.assert_close``).
+    """
+    val, err = {}, {}
+    with np.errstate(all='ignore'):
+        for i in dag.reachable(roots):
+            op, a = dag.op[i], dag.args[i]
+            if op == ir.CONST:
+                v, e = a[0], 0.0
+            elif op == ir.INPUT:
+                v, e = inputs(*a), 0.0
+            elif op in (ir.ADD, ir.SUB):
+                v = val[a[0]] + val[a[1]] if op == ir.ADD \
+                    else val[a[0]] - val[a[1]]
+                e = err[a[0]] + err[a[1]]
+            elif op == ir.MUL:
+                x, y = val[a[0]], val[a[1]]
+                v = x*y
+                e = np.abs(y)*err[a[0]] + np.abs(x)*err[a[1]]
+            elif op == ir.DIV:
+                x, y = val[a[0]], val[a[1]]
+                v = x/y
+                e = err[a[0]]/np.abs(y) + np.abs(v/y)*err[a[1]]
+            elif op == ir.NEG:
+                v, e = -val[a[0]], err[a[0]]
+            elif op == ir.POWI:
+                x = val[a[0]]
+                v = x**a[1]
+                e = a[1]*np.abs(x**(a[1] - 1))*err[a[0]]
+            elif op == ir.POW:
+                x, y = val[a[0]], val[a[1]]
+                v = np.power(x, y)
+                e = np.abs(v*y/x)*err[a[0]] + np.abs(v*np.log(np.abs(x)))*err[a[1]]
+            elif op in (ir.MAX, ir.MIN):
+                pick = np.maximum if op == ir.MAX else np.minimum
+                v = pick(val[a[0]], val[a[1]])
+                e = np.maximum(err[a[0]], err[a[1]])
+            elif op == ir.ATAN2:
+                y, x = val[a[0]], val[a[1]]
+                v = np.arctan2(y, x)
+                r2 = x*x + y*y
+                e = (np.abs(x)*err[a[0]] + np.abs(y)*err[a[1]])/r2
+            else:
+                x = val[a[0]]
+                v = _UN[op](x)
+                e = np.abs(_DUN[op](x, v))*err[a[0]]
+            val[i] = v
+            # one rounding of the operation's own result (2 for libm calls)
+            err[i] = e + np.abs(v)*(2.0 if op in _UN or op in (
+                ir.POW, ir.ATAN2) else (0.0 if op in (ir.CONST, ir.INPUT,
+                                                      ir.NEG) else 1.0))
+    return [val[r] for r in roots], [err[r] for r in roots]
+
+
+def error_bounds(col, free, nodes=None):
+    """Per-entry rounding-error bounds (units of round-off) of
+    ``constraints(free)`` and ``jacobian(free)`` in the reference's layouts;
+    ``nodes``: only these constraint nodes -> ``con (M, len(nodes))``,
+    ``jac (len(nodes), P)`` plus the instance tails."""
+    prog = col._build_program()
+    inputs, count = _input_getter(col, free, nodes)
+    ones = np.ones(count)
+    _, ce = evaluate_with_error_bound(prog.dag, prog.con_out, inputs)
+    _, je = evaluate_with_error_bound(prog.dag, prog.jac_out, inputs)
+    _, ice = evaluate_with_error_bound(prog.dag, prog.inst_con_out, inputs)
+    _, ije = evaluate_with_error_bound(prog.dag, prog.inst_jac_out, inputs)
+    con = np.stack([np.atleast_1d(c)*ones for c in ce]) if ce \
+        else np.zeros((0, count))
+    jac = np.stack([np.atleast_1d(v)*ones for v in je], axis=1) if je \
+        else np.zeros((count, 0))
+    ic, ij = np.array(ice, dtype=float), np.array(ije, dtype=float)
+    if nodes is None:
+        return np.concatenate((con.ravel(), ic)), \
+            np.concatenate((jac.ravel(), ij))
+    return con, jac, ic, ij
+
+
+def _input_getter(col, free, nodes=None):
+    prog = col._build_program()
+    N, n, q = col.num_collocation_nodes, prog.n, prog.q
+    free = np.asarray(free, dtype=float)
+    known = np.array([col.known_trajectory_map[f](free)
+                      if callable(col.known_trajectory_map[f])
+                      else col.known_trajectory_map[f]
+                      for f in col.known_input_trajectories], dtype=float)
+    tail = free[(n + q)*N:]
+    kpar = [float(col.known_parameter_map[p]) for p in col.known_parameters]
+    sel = slice(None) if nodes is None else np.asarray(nodes)
+
+    def row(r):
+        src, k = prog.rows[r]
+        return free[k*N:(k + 1)*N] if src == 'free' else known[k]
+
+    def inputs(kind, idx):
+        if kind in ('cur', 'adj'):
+            off = prog.cur_offset if kind == 'cur' else prog.adj_offset
+            return row(idx)[off:off + N - 1][sel]
+        if kind == 'par':
+            src, k = prog.pars[idx]
+            return kpar[k] if src == 'known' else tail[k]
+        if kind == 'h':
+            return col.node_time_interval if prog.h[0] == 'fixed' \
+                else tail[prog.h[1]]
+        if kind == 'free':
+            f = col._inst_atoms[idx]
+            return free[col.instance_constraints_free_index_map[f]]
+        raise AssertionError(kind)
+
+    return inputs, (N - 1 if nodes is None else len(sel))
+
+
 def evaluate_collocator(col, free):
     """constraints(free), jacobian(free) of an ``opty_amd.ConstraintCollocator``
     through the interpreter (layouts as the reference's)."""

@@ -49,7 +49,8 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'elementary_mid_small', 'delay_be_small', 'delay_mid_small',
          'odd_block_be_small', 'odd_block_mid_small',
          'states_only_mid_small']
-LARGE = {'config2_pendulum': 499, 'config3_10link': 4999}
+LARGE = {'config2_pendulum': 499, 'config3_10link': 4999,
+         'config5_standin_24link': 4999}
 
 
 def sample_nodes(num_con_nodes, stride):

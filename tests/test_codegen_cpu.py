@@ -38,8 +38,11 @@ def test_program_matches_reference(name):
                        'unknown_trajectories')):
         assert [str(s) for s in getattr(col, attr)] == meta[key], attr
     con, jac = dag_interp.evaluate_collocator(col, z['free'])
-    gu.assert_close(con, z['con'], 1e-10, what='con')
-    gu.assert_close(jac, z['jac'], 1e-10, what='jac')
+    cb, jb = gu.error_bounds(col, z['free'])
+    gu.assert_close(con, z['con'], 1e-10, what=name + ' con (interp)',
+                    bound=cb)
+    gu.assert_close(jac, z['jac'], 1e-10, what=name + ' jac (interp)',
+                    bound=jb)
     r, c = col._instance_constraints_jacobian_indices()
     if meta['nnz_inst']:
         np.testing.assert_array_equal(r, z['rows'][-meta['nnz_inst']:])

@@ -36,8 +36,9 @@ def test_golden_full(name):
     assert rows.dtype == np.int64 and cols.dtype == np.int64
     np.testing.assert_array_equal(rows, z['rows'])
     np.testing.assert_array_equal(cols, z['cols'])
-    gu.assert_close(con, z['con'], RTOL, what=name + ' con')
-    gu.assert_close(jac, z['jac'], RTOL, what=name + ' jac')
+    cb, jb = gu.error_bounds(col, z['free'])
+    gu.assert_close(con, z['con'], RTOL, what=name + ' con', bound=cb)
+    gu.assert_close(jac, z['jac'], RTOL, what=name + ' jac', bound=jb)
 
 
 @pytest.mark.parametrize('name', gu.SAMPLED)
@@ -58,8 +59,12 @@ def test_golden_sampled(name):
     nodes = z['nodes']
     blk = jac[:P*(N - 1)].reshape(N - 1, P)
     cb = con[:M*(N - 1)].reshape(M, N - 1)
-    gu.assert_close(blk[nodes], z['jac_nodes'], RTOL, what='jac nodes')
-    gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL, what='con nodes')
+    # per-entry floors from the entries' own rounding-error bounds
+    cbn, jbn, icb, ijb = gu.error_bounds(col, free, nodes)
+    gu.assert_close(blk[nodes], z['jac_nodes'], RTOL,
+                    what=name + ' jac nodes', bound=jbn)
+    gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL,
+                    what=name + ' con nodes', bound=cbn)
     np.testing.assert_array_equal(
         rows[:P*(N - 1)].reshape(N - 1, P)[nodes], z['rows_nodes'])
     np.testing.assert_array_equal(
@@ -72,8 +77,10 @@ def test_golden_sampled(name):
                     scale=float(np.abs(cb).sum())/M, what='con sums')
     gu.assert_close(np.abs(blk).sum(), z['jac_abs_sum'][0], 1e-9,
                     what='jac abs sum')
-    gu.assert_close(con[M*(N - 1):], z['con_tail'], RTOL, what='con tail')
-    gu.assert_close(jac[P*(N - 1):], z['jac_tail'], RTOL, what='jac tail')
+    gu.assert_close(con[M*(N - 1):], z['con_tail'], RTOL, what='con tail',
+                    bound=icb)
+    gu.assert_close(jac[P*(N - 1):], z['jac_tail'], RTOL, what='jac tail',
+                    bound=ijb)
     np.testing.assert_array_equal(rows[P*(N - 1):], z['rows_tail'])
     np.testing.assert_array_equal(cols[P*(N - 1):], z['cols_tail'])
 
@@ -99,10 +106,11 @@ def test_against_oracle_ragged(name, N):
                                   variable_duration=col._variable_duration)
         c_ref = orc.generate_constraint_function()(free)
         j_ref = orc.generate_jacobian_function()(free)
+        cb, jb = gu.error_bounds(col, free)
         gu.assert_close(col.generate_constraint_function()(free), c_ref,
-                        RTOL, what='con')
+                        RTOL, what='ragged con', bound=cb)
         gu.assert_close(col.generate_jacobian_function()(free), j_ref, RTOL,
-                        what='jac')
+                        what='ragged jac', bound=jb)
     r_ref, k_ref = orc.jacobian_indices()
     rows, cols = col.jacobian_indices()
     np.testing.assert_array_equal(rows, r_ref)
@@ -228,6 +236,72 @@ def test_parameter_and_interval_updates_refresh_invariants():
     orc = OracleCollocator(name='pend3_link_midpoint', **kw2)
     gu.assert_close(jac(free), orc.generate_jacobian_function()(free), RTOL,
                     what='jac after update')
+
+
+def test_known_maps_are_re_read_on_every_call():
+    """The reference reads ``known_parameter_map`` / ``known_trajectory_map``
+    on every call (``_merge_fixed_free``, ``opty/direct_collocation.py:
+    2891-2926``); its gallery changes a known parameter between two solves
+    (``plot_human_gait.py``).  A changed dictionary value and an in-place edit
+    of a known trajectory array must show up in the next evaluation."""
+    from oracle.collocation_oracle import OracleCollocator
+    import opty_amd
+    kw = problems.mass_spring_damper(num_nodes=150)
+    col = opty_amd.ConstraintCollocator(**kw)
+    con = col.generate_constraint_function()
+    jac = col.generate_jacobian_function()
+    free = problems.make_free(col.num_free, seed=2)
+
+    def check(tag):
+        orc = OracleCollocator(name='msd_mutated', **kw)
+        gu.assert_close(con(free), orc.generate_constraint_function()(free),
+                        RTOL, what='con ' + tag)
+        gu.assert_close(jac(free), orc.generate_jacobian_function()(free),
+                        RTOL, what='jac ' + tag)
+
+    check('initial')
+    m = list(kw['known_parameter_map'])[0]
+    col.known_parameter_map[m] = 1.625            # dictionary value
+    assert kw['known_parameter_map'][m] == 1.625   # same dict object
+    check('parameter changed')
+    f = list(kw['known_trajectory_map'])[0]
+    col.known_trajectory_map[f][:] *= -0.5         # in-place array edit
+    check('trajectory edited in place')
+    col.known_trajectory_map[f] = np.cos(np.arange(150.0))   # new array
+    check('trajectory replaced')
+
+
+def test_stream_switch_orders_the_invariant_table():
+    """A handle whose node-invariant table depends on ``free`` (unknown
+    parameters, variable h), used alternately on two streams: every launch
+    is ordered behind the previous stream's work (opty_hip_set_stream)."""
+    import torch
+    from opty_amd import hip_backend as hb
+    col = _collocator('pend2_link_vardur_unkmass_small', num_nodes=20000)
+    hip = col.hip
+    dev = torch.device('cuda:0')
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    frees = [torch.from_numpy(problems.make_free(
+        col.num_free, seed=s, variable_duration=True,
+        interval=0.01*(1 + s))).to(dev) for s in range(2)]
+    jacs = [torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+            for _ in range(2)]
+    want = []
+    for f in frees:
+        j = torch.empty_like(jacs[0])
+        hip.set_stream(None)
+        hip.eval_jac(f, j, hb.DEVICE)
+        hip.synchronize()
+        want.append(j)
+    torch.cuda.synchronize()
+    for rep in range(20):
+        for k in range(2):
+            hip.set_stream(streams[k].cuda_stream)
+            hip.eval_jac(frees[k], jacs[k], hb.DEVICE)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(jacs[k], want[k])
+    hip.set_stream(None)
 
 
 def test_pinned_host_buffers():
@@ -422,6 +496,12 @@ def test_golden_window_embedded_at_full_size(name, N, layout):
     tail = small[nrows*n_small:]
     gcon = z['con'][:M*(n_small - 1)].reshape(M, n_small - 1)
     gjac = z['jac'][:P*(n_small - 1)].reshape(n_small - 1, P)
+    # per-entry floors: the window holds the small problem's inputs, so the
+    # small problem's error bounds apply entry for entry
+    bcon, bjac = gu.error_bounds(
+        opty_amd.ConstraintCollocator(**problems.build(name)), small)
+    bcon = bcon[:M*(n_small - 1)].reshape(M, n_small - 1)
+    bjac = bjac[:P*(n_small - 1)].reshape(n_small - 1, P)
     if layout == 'csr':
         prog = col._build_program()
         sel = [j*C + k for j, k in prog.pattern]
@@ -437,18 +517,19 @@ def test_golden_window_embedded_at_full_size(name, N, layout):
         con = con_f(free)[:M*(N - 1)].reshape(M, N - 1)
         jac = jac_f(free)
         gu.assert_close(con[:, off:off + n_small - 1], gcon, RTOL,
-                        what='%s con window @%d' % (name, off))
+                        what='%s con window' % name, bound=bcon)
         if layout == 'coo':
             win = jac[:P*(N - 1)].reshape(N - 1, P)[off:off + n_small - 1]
             gu.assert_close(win, gjac, RTOL,
-                            what='%s jac window @%d' % (name, off))
+                            what='%s jac window' % name, bound=bjac)
         else:
             for j in range(M):
                 L = rs[j + 1] - rs[j]
                 blk = jac[rs[j]*(N - 1):rs[j + 1]*(N - 1)].reshape(N - 1, L)
                 gu.assert_close(blk[off:off + n_small - 1],
                                 gjac[:, sel[rs[j]:rs[j + 1]]], RTOL,
-                                what='%s csr row %d @%d' % (name, j, off))
+                                what='%s csr window' % name,
+                                bound=bjac[:, sel[rs[j]:rs[j + 1]]])
 
 
 @pytest.mark.parametrize('name', ['config3_10link_small',
@@ -503,11 +584,15 @@ def test_million_node_problem_device_windows():
     gjac = z['jac'].reshape(n_small - 1, P)
     cv = con.view(M, N - 1)
     jv = jac.view(N - 1, P)
+    bcon, bjac = gu.error_bounds(
+        opty_amd.ConstraintCollocator(
+            **problems.build('config3_10link_small')), z['free'])
+    bcon, bjac = bcon.reshape(M, n_small - 1), bjac.reshape(n_small - 1, P)
     for off in offsets:
         gu.assert_close(cv[:, off:off + n_small - 1].cpu().numpy(), gcon,
-                        RTOL, what='con window @%d' % off)
+                        RTOL, what='1M-node con window', bound=bcon)
         gu.assert_close(jv[off:off + n_small - 1].cpu().numpy(), gjac, RTOL,
-                        what='jac window @%d' % off)
+                        what='1M-node jac window', bound=bjac)
     # the nodes in between are finite and not left unwritten
     probe = jv[::9973]
     assert torch.isfinite(probe).all()

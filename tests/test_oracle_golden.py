@@ -40,10 +40,14 @@ def test_oracle_matches_reference_full(name):
     r2, c2 = orc.jacobian_indices_loop()
     np.testing.assert_array_equal(r2, z['rows'])
     np.testing.assert_array_equal(c2, z['cols'])
+    # 1e-12 relative per entry, floors from the entries' own error bounds
+    import opty_amd
+    cb, jb = gu.error_bounds(
+        opty_amd.ConstraintCollocator(**problems.build(name)), free)
     gu.assert_close(orc.generate_constraint_function()(free), z['con'],
-                    1e-12, what='con')
+                    1e-12, what=name + ' con (oracle)', bound=cb)
     gu.assert_close(orc.generate_jacobian_function()(free), z['jac'], 1e-12,
-                    what='jac')
+                    what=name + ' jac (oracle)', bound=jb)
 
 
 def test_oracle_matches_reference_config2_full_size():

@@ -1,32 +1,45 @@
-"""The node-sharding logic (partition, one-node halo slabs, all-gather
-re-assembly) on 2 CPU processes with the ``gloo`` backend.  The local evaluator
-is the oracle (test infrastructure) -- on GPUs it is the HIP collocator; the
-sharding code is identical."""
+"""The node-sharding logic of BASELINE config 4 (partition with unequal
+shards, evaluation of a node range from the GLOBAL free vector, point-to-point
+gather-v with in-place Jacobian slices and equation-major constraint
+placement, all-gather, the shared host vector) on CPU processes with the
+``gloo`` backend.  The shard evaluator is the oracle (test infrastructure) --
+on GPUs it is ``opty_hip_eval_shard``; the partition and exchange code is the
+same."""
 import os
 import socket
 
 import numpy as np
 import pytest
+import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from opty_amd import problems
-from opty_amd.sharded import ShardedCollocator, partition_nodes
+from opty_amd.sharded import (ShardedCollocator, SharedHostVector,
+                              partition_nodes, slab_of)
 
 
-class _OracleLocal(object):
-    def __init__(self, kw):
+class _OracleShard(object):
+    """Evaluates constraint nodes [a, b) of the global problem with the
+    oracle built for the (b - a + 1)-node slab problem."""
+
+    def __init__(self, kw, a, b):
         from oracle.collocation_oracle import OracleCollocator
-        self.o = OracleCollocator(name='shard', **kw)
-        self.num_free = self.o.num_free
-        self.num_states = self.o.n
-        self.num_unknown_input_trajectories = self.o.q
+        self.N = kw['num_collocation_nodes']
+        known = {k: np.asarray(v)[a:b + 1]
+                 for k, v in kw.get('known_trajectory_map', {}).items()}
+        self.o = OracleCollocator(name='shard', **dict(
+            kw, num_collocation_nodes=b - a + 1, known_trajectory_map=known))
+        self.con = self.o.generate_constraint_function()
+        self.jac = self.o.generate_jacobian_function()
+        self.rows = self.o.n + self.o.q
+        self.num_free_global = self.o.num_free + self.rows*(self.N -
+                                                            (b - a + 1))
 
-    def generate_constraint_function(self):
-        return self.o.generate_constraint_function()
-
-    def generate_jacobian_function(self):
-        return self.o.generate_jacobian_function()
+    def __call__(self, free, con2d, jac1d, a, b):
+        slab = slab_of(free.numpy(), self.N, self.rows, a, b)
+        con2d.copy_(torch.from_numpy(self.con(slab).reshape(self.o.M, b - a)))
+        jac1d.copy_(torch.from_numpy(np.asarray(self.jac(slab))))
 
 
 def _free_port():
@@ -44,42 +57,93 @@ def _worker(rank, world, port, name, N, out):
     try:
         factory, fkw = problems.CONFIGS[name]
         kw = factory(**dict(fkw, num_nodes=N))
-        sh = ShardedCollocator(local_factory=_OracleLocal, **kw)
-        free = problems.make_free(
-            sh.local.o.num_free - (sh.b - sh.a + 1)*(sh.local.o.n +
-                                                     sh.local.o.q) +
-            N*(sh.local.o.n + sh.local.o.q), seed=7,
-            variable_duration=sh.local.o.variable_duration)
-        con = sh.constraints(free)
-        jac = sh.jacobian(free)
-        if rank == 0:
-            np.savez(out, con=con, jac=jac, free=free)
+        a, b = partition_nodes(N - 1, world)[rank]
+        ev = _OracleShard(kw, a, b)
+        sh = ShardedCollocator(evaluator=ev, block_shape=(ev.o.M,
+                                                          ev.o.M*ev.o.C),
+                               **kw)
+        sh.set_num_free(ev.num_free_global)
+        assert (sh.a, sh.b) == (a, b)
+        free = torch.from_numpy(problems.make_free(
+            ev.num_free_global, seed=7,
+            variable_duration=ev.o.variable_duration))
+        # rank 0 holds `free`; the others receive it (RCCL broadcast on GPUs)
+        if rank != 0:
+            free = torch.zeros_like(free)
+        sh.broadcast_free(free, src=0)
+        # (1) gather-v to rank 1 with the destination evaluating in place
+        sh.evaluate(free, in_place=(rank == world - 1))
+        got = sh.gather(dst=world - 1)
+        assert (got is None) == (rank != world - 1)
+        if got is not None:
+            g_con, g_jac = got[0].clone(), got[1].clone()
+        # (2) all-gather: the full vectors on every rank
+        sh.evaluate(free)
+        a_con, a_jac = sh.all_gather()
+        # (3) every rank writes its shard into the node-wide host vectors
+        ncn = N - 1
+        con_host = SharedHostVector('opty_t_con_%d' % port, sh.M*ncn, rank,
+                                    pin=False)
+        jac_host = SharedHostVector('opty_t_jac_%d' % port, sh.P*ncn, rank,
+                                    pin=False)
+        sh.to_host(con_host, jac_host)
+        dist.barrier()
+        np.savez(out % rank, a_con=a_con.numpy(), a_jac=a_jac.numpy(),
+                 free=free.numpy(), h_con=np.array(con_host.array),
+                 h_jac=np.array(jac_host.array),
+                 **({'g_con': g_con.numpy(), 'g_jac': g_jac.numpy()}
+                    if got is not None else {}))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('name,N', [('msd_be_small', 24),
-                                    ('pend3_link_midpoint_small', 31),
-                                    ('pend2_link_vardur_unkmass_small', 26)])
-def test_two_rank_shards_reassemble_to_full(tmp_path, name, N):
+@pytest.mark.parametrize('name,N,world', [
+    ('msd_be_small', 24, 2),                        # 23 nodes: 12 + 11
+    ('pend3_link_midpoint_small', 32, 2),
+    ('pend2_link_vardur_unkmass_small', 26, 3)])    # 25 nodes: 9 + 8 + 8
+def test_shards_reassemble_to_full(tmp_path, name, N, world):
     from oracle.collocation_oracle import OracleCollocator
-    out = str(tmp_path/'gathered.npz')
-    mp.spawn(_worker, args=(2, _free_port(), name, N, out), nprocs=2,
-             join=True)
-    z = np.load(out)
+    assert (N - 1) % world != 0, 'the test wants unequal shards'
+    out = str(tmp_path/'rank%d.npz')
+    mp.spawn(_worker, args=(world, _free_port(), name, N, out),
+             nprocs=world, join=True)
     factory, fkw = problems.CONFIGS[name]
     full = OracleCollocator(name='shard', **factory(**dict(fkw,
                                                            num_nodes=N)))
-    np.testing.assert_allclose(
-        z['con'], full.generate_constraint_function()(z['free']),
-        rtol=1e-13, atol=1e-13)
-    np.testing.assert_allclose(
-        z['jac'], full.generate_jacobian_function()(z['free']),
-        rtol=1e-13, atol=1e-13)
+    z = [np.load(out % r) for r in range(world)]
+    free = z[0]['free']
+    c_ref = full.generate_constraint_function()(free)
+    j_ref = np.asarray(full.generate_jacobian_function()(free))
+    kw = dict(rtol=1e-13, atol=1e-13)
+    for r in range(world):
+        np.testing.assert_array_equal(z[r]['free'], free)   # broadcast
+        np.testing.assert_allclose(z[r]['a_con'], c_ref, **kw)
+        np.testing.assert_allclose(z[r]['a_jac'], j_ref, **kw)
+        np.testing.assert_allclose(z[r]['h_con'], c_ref, **kw)
+        np.testing.assert_allclose(z[r]['h_jac'], j_ref, **kw)
+        assert ('g_con' in z[r].files) == (r == world - 1)
+    np.testing.assert_allclose(z[world - 1]['g_con'], c_ref, **kw)
+    np.testing.assert_allclose(z[world - 1]['g_jac'], j_ref, **kw)
 
 
 def test_partition():
     assert partition_nodes(10, 3) == [(0, 4), (4, 7), (7, 10)]
     assert partition_nodes(99999, 8)[-1][1] == 99999
     sizes = [b - a for a, b in partition_nodes(99999, 8)]
-    assert max(sizes) - min(sizes) <= 1
+    assert max(sizes) - min(sizes) <= 1 and sum(sizes) == 99999
+
+
+def test_slab_is_a_collocation_problem():
+    free = np.arange(3*7 + 2, dtype=float)          # 3 rows, 7 nodes, 2 tail
+    slab = slab_of(free, 7, 3, 2, 5)
+    want = np.concatenate([free[2:6], free[9:13], free[16:20], free[21:]])
+    np.testing.assert_array_equal(slab, want)
+
+
+def test_csr_and_instance_constraints_are_rejected():
+    kw = problems.build('config2_pendulum_small')
+    with pytest.raises(NotImplementedError):
+        ShardedCollocator(rank=0, world_size=2, **kw)
+    kw = problems.build('msd_be_small')
+    with pytest.raises(NotImplementedError):
+        ShardedCollocator(rank=0, world_size=2, jacobian_layout='csr', **kw)

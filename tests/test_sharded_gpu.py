@@ -1,0 +1,188 @@
+"""BASELINE config 4 on the GPU: node shards evaluated by ``opty_hip_eval_shard``
+from the global free vector, re-assembled by the point-to-point gather-v, and
+held to the reference's golden vectors of config 3 (sampled nodes +
+checksums).  A 1-GPU box runs the ranks oversubscribed on ``cuda:0`` with a
+``gloo`` rendezvous (RCCL refuses duplicate devices); the evaluation, the
+partition and the exchange logic are the ones ``bench.py --gpus N`` runs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from opty_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+RTOL = 1e-10
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_ranges_written_in_place_equal_the_whole_evaluation():
+    """Three unequal node ranges, each written straight into the global
+    equation-major / node-major vectors (con_stride = N - 1), give bit for bit
+    what one whole-problem launch of the same handle gives; a dense
+    (M x nodes) block of one range equals the same slice."""
+    import torch
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    factory, fkw = problems.CONFIGS['pend3_link_midpoint_small']
+    kw = factory(**dict(fkw, num_nodes=301))
+    col = opty_amd.ConstraintCollocator(**kw)
+    hip = col.hip
+    dev = torch.device('cuda:0')
+    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    prog = col._build_program()
+    M, P, ncn = prog.M, prog.P, col.num_collocation_nodes - 1
+    free = torch.from_numpy(problems.make_free(col.num_free, seed=4)).to(dev)
+    con = torch.empty(M*ncn, dtype=torch.float64, device=dev)
+    jac = torch.empty(P*ncn, dtype=torch.float64, device=dev)
+    hip.eval_con_jac(free, con, jac, hb.DEVICE)
+    con2 = torch.full_like(con, np.nan)
+    jac2 = torch.full_like(jac, np.nan)
+    for a, b in ((0, 100), (100, 237), (237, 300)):
+        hip.eval_shard(hb.EVAL_FUSED, free, con2[a:], ncn, jac2[a*P:], a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(con, con2) and torch.equal(jac, jac2)
+    # separate kernels, dense local block
+    a, b = 64, 191
+    blk = torch.full((M, b - a), np.nan, dtype=torch.float64, device=dev)
+    jl = torch.full(((b - a)*P,), np.nan, dtype=torch.float64, device=dev)
+    hip.eval_shard(hb.EVAL_PAIR, free, blk, b - a, jl, a, b)
+    c_sep = torch.empty_like(con)
+    j_sep = torch.empty_like(jac)
+    hip.eval_con(free, c_sep, hb.DEVICE)
+    hip.eval_jac(free, j_sep, hb.DEVICE)
+    torch.cuda.synchronize()
+    assert torch.equal(blk, c_sep.view(M, ncn)[:, a:b])
+    assert torch.equal(jl, j_sep[a*P:b*P])
+    # indices of a range == that slice of the global enumeration
+    rows, cols = col.jacobian_indices()
+    r = np.empty((b - a)*P, dtype=np.int64)
+    c = np.empty_like(r)
+    hip.jacobian_indices_range(a, b, r, c, hb.HOST)
+    np.testing.assert_array_equal(r, rows[a*P:b*P])
+    np.testing.assert_array_equal(c, cols[a*P:b*P])
+    # misuse
+    with pytest.raises(hb.HipBackendError):
+        hip.eval_shard(hb.EVAL_FUSED, free, con2, ncn, jac2, 10, ncn + 1)
+    with pytest.raises(hb.HipBackendError):
+        hip.eval_shard(hb.EVAL_FUSED, free, con2, 5, jac2, 0, 10)
+    hip.set_stream(None)
+
+
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from opty_amd.sharded import ShardedCollocator, SharedHostVector
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        kw = problems.build('config3_10link')
+        sh = ShardedCollocator(device=dev, **kw)
+        sh.collocator.hip.set_stream(
+            torch.cuda.current_stream().cuda_stream)
+        meta, _ = gu.load('config3_10link')
+        free = torch.from_numpy(problems.make_free(
+            sh.collocator.num_free, seed=meta['seed'])).to(dev)
+        if rank != 0:
+            free.zero_()
+        # gloo broadcasts host memory; on a multi-GPU node this is RCCL
+        host = free.cpu()
+        dist.broadcast(host, 0)
+        free.copy_(host)
+        sh.evaluate(free, in_place=(rank == 0))
+        got = sh.gather(0)
+        ncn = sh.N - 1
+        con_host = SharedHostVector('opty_t_con_%d' % port, sh.M*ncn, rank)
+        jac_host = SharedHostVector('opty_t_jac_%d' % port, sh.P*ncn, rank)
+        sh.to_host(con_host, jac_host)
+        torch.cuda.synchronize()
+        dist.barrier()
+        rows, cols = sh.jacobian_indices_local()
+        if rank == 0:
+            con, jac = got
+            np.savez(out, con=con.cpu().numpy(), jac=jac.cpu().numpy(),
+                     h_con=np.array(con_host.array),
+                     h_jac=np.array(jac_host.array))
+        np.savez(out + '.idx%d' % rank, rows=rows, cols=cols,
+                 ab=np.array([sh.a, sh.b]))
+        con_host.close()
+        jac_host.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_config3_and_gather_to_the_reference(tmp_path):
+    """N - 1 = 99 999 nodes over 2 ranks (50 000 + 49 999): gathered vectors
+    and the shared host vectors vs the reference's golden samples."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path/'gathered.npz')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    meta, z = gu.load('config3_10link')
+    N, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    got = np.load(out)
+    nodes = z['nodes']
+    for tag in ('', 'h_'):
+        con, jac = got[tag + 'con'], got[tag + 'jac']
+        assert con.shape == (M*(N - 1),) and jac.shape == (P*(N - 1),)
+        blk = jac.reshape(N - 1, P)
+        cb = con.reshape(M, N - 1)
+        gu.assert_close(blk[nodes], z['jac_nodes'], RTOL,
+                        what=tag + 'jac nodes')
+        gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL,
+                        what=tag + 'con nodes')
+        scale = float(z['jac_abs_sum'][0])
+        gu.assert_close(blk.sum(axis=0), z['jac_entry_sums'], 1e-9,
+                        scale=scale/P, what=tag + 'jac entry sums')
+        gu.assert_close(cb.sum(axis=1), z['con_eq_sums'], 1e-9,
+                        scale=float(np.abs(cb).sum())/M,
+                        what=tag + 'con sums')
+    # shard indices at the sampled nodes
+    for rank in range(2):
+        zi = np.load(out + '.idx%d.npz' % rank)
+        a, b = zi['ab']
+        sel = nodes[(nodes >= a) & (nodes < b)]
+        pick = np.isin(nodes, sel)
+        np.testing.assert_array_equal(
+            zi['rows'].reshape(b - a, P)[sel - a], z['rows_nodes'][pick])
+        np.testing.assert_array_equal(
+            zi['cols'].reshape(b - a, P)[sel - a], z['cols_nodes'][pick])
+
+
+def test_bench_strong_scaling_two_ranks():
+    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run,
+    oversubscribed here): strong scaling of ONE problem, all three variants
+    in the line."""
+    env = dict(os.environ, OPTY_BENCH_OVERSUBSCRIBE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'),
+           '--gpus', '2', '--steps', '5', '--warmup', '2', '--prewarm-ms',
+           '20', '--no-cpu-baseline']
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO,
+                          env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['scaling'] == 'strong' and res['n_gpus'] == 2
+    assert res['config']['nodes_per_launch'] == 50000
+    assert set(res['config']['variants']) == {'gather', 'to_host'}
+    assert res['value'] > 0 and res['roofline']['frac'] > 0
