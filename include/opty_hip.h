@@ -229,6 +229,41 @@ int opty_hip_objective_set_stream(opty_hip_objective *o, void *hip_stream);
 int opty_hip_objective_eval(opty_hip_objective *o, const double *free,
                             double *value, double *grad, int32_t mem);
 
+/* ---- plain matrix functions: the reference's plugin call shape ---------------
+ * `f = ufuncify_matrix(args, expr, const=...)`, `f(result, *num_args)`
+ * (opty/utils.py:639-640; argument contract :610-617, :778-807): a rows x cols
+ * matrix of expressions evaluated for n independent argument rows, the
+ * generated `eval_matrix` + `eval_matrix_loop` pair (opty/utils.py:483-529)
+ * as one gfx950 kernel (`opty_jac` of a "matrix program", lane = evaluation
+ * row, row-major (n, rows*cols) output through the same tile flush as a
+ * Jacobian block) plus `opty_uni` for sub-expressions of the const
+ * arguments alone. */
+typedef struct opty_hip_matrix opty_hip_matrix;
+
+typedef struct opty_hip_matrix_desc {
+    int32_t num_vec;        /* vector arguments: one double per row           */
+    int32_t num_const;      /* const arguments: one double per call           */
+    int32_t rows, cols;     /* shape of the matrix                            */
+    int32_t wgs_per_block;  /* launch geometry of opty_jac (from the emitter) */
+    int32_t waves_per_wg;
+    int32_t num_uniform;    /* entries of the node-invariant table            */
+    int32_t device;         /* HIP device ordinal                             */
+} opty_hip_matrix_desc;
+
+int opty_hip_matrix_create(const opty_hip_matrix_desc *desc,
+                           const char *code_object_path,
+                           opty_hip_matrix **out);
+int opty_hip_matrix_destroy(opty_hip_matrix *m);
+int opty_hip_matrix_set_stream(opty_hip_matrix *m, void *hip_stream);
+/* result: n*rows*cols doubles, result[i*rows*cols + r*cols + c];
+ * vec_args: HOST array of num_vec pointers, each to n contiguous doubles in
+ * `mem` memory (n >= 1); const_args: num_const doubles in HOST memory (passed
+ * by value in the reference).  Synchronous for OPTY_HIP_HOST, enqueued on the
+ * handle's stream for OPTY_HIP_DEVICE. */
+int opty_hip_matrix_eval(opty_hip_matrix *m, double *result,
+                         const double *const *vec_args,
+                         const double *const_args, int64_t n, int32_t mem);
+
 /* Page-locked host memory for OPTY_HIP_HOST callers: output arrays that live
  * in it (the persistent Jacobian value buffer the reference keeps,
  * opty/direct_collocation.py:2814) are copied back at full PCIe rate. */

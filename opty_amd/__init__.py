@@ -3,9 +3,10 @@ direct collocation (drop-in for ``opty.ConstraintCollocator`` / ``Problem``
 on the hot path)."""
 
 from .direct_collocation import ConstraintCollocator, Problem
-from .utils import parse_free
+from .utils import parse_free, ufuncify_matrix
 from .objective import create_objective_function
 
 __all__ = ['ConstraintCollocator', 'Problem', 'parse_free',
+           'ufuncify_matrix',
            'create_objective_function']
 __version__ = '0.1.0'

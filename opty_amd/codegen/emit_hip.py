@@ -868,6 +868,30 @@ def _fit_one_round(auto_groups, con_waves, node_blocks):
     return auto_groups
 
 
+def emit_matrix_module(prog, opts=None):
+    """Module of a *matrix program* (``program.matrix_program``: a plain
+    ``(rows x cols)`` matrix of expressions evaluated for ``n`` independent
+    argument rows -- the call shape of the reference's ``ufuncify_matrix``,
+    ``opty/utils.py:639-640``): only ``opty_jac`` (the matrix entries, staged
+    and flushed like a Jacobian block) and ``opty_uni``."""
+    opts = opts or EmitOptions()
+    w = _ModuleWriter(prog, opts)
+    groups = w.group_ranges()
+    src, kmeta = w.kernel('opty_jac', groups, [[] for _ in groups],
+                          opts.waves)
+    usrc, num_uniform, dynamic = w.uniform_kernel()
+    assert not dynamic
+    head = ['// generated by opty_amd.codegen.emit_hip (matrix program) -- '
+            'do not edit', '// %s' % opts.key(),
+            '#define OPTY_STORE_AUX %d' % opts.store_aux,
+            '#include "opty_device.h"', '']
+    source = '\n'.join(head + [src, '', usrc, ''])
+    meta = dict(kernels={'jac': kmeta}, chunk=opts.chunk, P=prog.P,
+                num_uniform=num_uniform, uniform_dynamic=False,
+                sha=hashlib.sha256(source.encode()).hexdigest())
+    return source, meta
+
+
 def emit_module(prog, opts=None, node_blocks=None):
     """Returns ``(source, meta)``; ``meta`` describes the launch geometry the
     runtime needs (waves per node block, size of the ``uni`` table, whether

@@ -165,6 +165,28 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
         pruned=bool(prune_zeros), layout=layout, row_start=row_start)
 
 
+def matrix_program(dag, outputs, num_vec, num_const, shape):
+    """Program of a plain matrix of expressions (the reference's
+    ``ufuncify_matrix`` call shape, ``opty/utils.py:639-640``): ``outputs`` are
+    the DAG nodes of the ``rows x cols`` entries, row-major, over the inputs
+    ``('cur', k)`` -- vector argument ``k`` (one value per evaluation row) --
+    and ``('par', k)`` -- constant argument ``k``.  The vector arguments are
+    the rows of one packed ``(num_vec, n)`` buffer that the kernels see as
+    their ``free`` vector with ``N = n``."""
+    rows, cols = shape
+    assert len(outputs) == rows*cols
+    return CollocationProgram(
+        dag=dag, con_out=[], jac_out=list(outputs), n=num_vec, m=0, q=0, r=0,
+        s=0, M=rows, C=cols, num_known_traj=0, num_known_par=num_const,
+        rows=[('free', k) for k in range(num_vec)],
+        pars=[('known', k) for k in range(num_const)], h=('fixed',),
+        method='matrix', cur_offset=0, adj_offset=0, inst_con_out=[],
+        inst_jac_out=[], num_inst_atoms=0,
+        pattern=[(j, k) for j in range(rows) for k in range(cols)],
+        pruned=False, layout='coo',
+        row_start=[j*cols for j in range(rows + 1)])
+
+
 def _column_key(n, q, method):
     """Sort key of wrt index k equal to the order of the free-vector column
     it differentiates with respect to (the closed form of

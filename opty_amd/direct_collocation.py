@@ -630,6 +630,115 @@ class ConstraintCollocator(object):
         pointers (the host callbacks do this on every call)."""
         self._sync_known(self._ensure_hip(), None)
 
+    # ------------------------------------------------------------------
+    # the reference's multi-argument closures, on the plugin call shape
+    # (opty/direct_collocation.py:2304-2446, :2692-2887)
+    # ------------------------------------------------------------------
+    def _multi_arg_dag(self):
+        """The discretised equations lowered over the reference's argument
+        list ``x_i(n), x_p|x_n(n), s_i(m)[, s_n(m)], parameters(p), h``
+        (``:2347-2359``): vector argument ``k`` is DAG input ``('cur', k)``,
+        the ``p + 1`` trailing scalars are the const arguments."""
+        from .codegen import ir
+        from .codegen.lower import Lowerer
+        be = self.integration_method == 'backward euler'
+        vec = (self.current_discrete_state_symbols +
+               (self.previous_discrete_state_symbols if be
+                else self.next_discrete_state_symbols) +
+               self.current_discrete_specified_symbols)
+        if not be:
+            vec += self.next_discrete_specified_symbols
+        const = self.parameters + (self.time_interval_symbol,)
+        dag = ir.DAG()
+        table = {s: dag.input('cur', k) for k, s in enumerate(vec)}
+        table.update({s: dag.input('par', k) for k, s in enumerate(const)})
+        low = Lowerer(dag, table)
+        con = [low.lower(e) for e in self.discrete_eom]
+        # r_i(x_i): d/dx_i through the argument that carries dr/dx
+        n, m = self.num_states, self.num_input_trajectories
+        chain = {}
+        for k, st, kd in self._implicit_chain():
+            chain[dag.input('cur', 2*n + k)] = [
+                (dag.input('cur', st), dag.input('cur', 2*n + kd))]
+            if not be:
+                chain[dag.input('cur', 2*n + m + k)] = [
+                    (dag.input('cur', n + st),
+                     dag.input('cur', 2*n + m + kd))]
+        return dag, table, con, len(vec), len(const), chain
+
+    def _multi_arg_values(self, state_values, specified_values,
+                          constant_values, interval_value):
+        """The reference closures' slicing of their four arguments into the
+        compiled function's argument list (``:2408-2437``, ``:2866-2887``)."""
+        N = self.num_collocation_nodes
+        assert state_values.shape == (self.num_states, N)
+        be = self.integration_method == 'backward euler'
+        cur = slice(1, None) if be else slice(None, -1)
+        adj = slice(None, -1) if be else slice(1, None)
+        args = [x for x in state_values[:, cur]]
+        args += [x for x in state_values[:, adj]]
+        specified_values = np.asarray(specified_values)
+        if specified_values.ndim == 2:
+            assert specified_values.shape == (self.num_input_trajectories, N)
+            args += [u for u in specified_values[:, cur]]
+            if not be:
+                args += [u for u in specified_values[:, adj]]
+        elif specified_values.ndim == 1 and specified_values.size != 0:
+            assert specified_values.shape == (N,)
+            args += [specified_values[cur]]
+            if not be:
+                args += [specified_values[adj]]
+        args = [np.ascontiguousarray(a, dtype=np.float64) for a in args]
+        return args + [float(c) for c in constant_values] + \
+            [float(interval_value)]
+
+    def _gen_multi_arg_con_func(self):
+        """Instantiates ``_multi_arg_con_func(state_values (n, N),
+        specified_values (m, N) or (N,), constant_values (p,),
+        interval_value) -> (M*(N-1),)``, equation-major, on top of the
+        plugin call shape ``f(result, *args)`` (:func:`opty_amd.utils.
+        ufuncify_matrix`) -- ``opty/direct_collocation.py:2304-2446``.  The
+        fused path (:meth:`generate_constraint_function`) does not go through
+        this."""
+        from .utils import _MatrixFunction
+        dag, _, con, nvec, nconst, _ = self._multi_arg_dag()
+        f = _MatrixFunction(dag, con, nvec, range(nvec, nvec + nconst),
+                            nvec + nconst, (self.num_eom, 1), self.tmp_dir,
+                            self.show_compile_output, self._device)
+
+        def constraints(state_values, specified_values, constant_values,
+                        interval_value):
+            args = self._multi_arg_values(state_values, specified_values,
+                                          constant_values, interval_value)
+            result = np.empty((self.num_collocation_nodes - 1, self.num_eom))
+            return f(result, *args).T.flatten()
+
+        self._multi_arg_con_func = constraints
+
+    def _gen_multi_arg_con_jac_func(self):
+        """Instantiates ``_multi_arg_con_jac_func(...) -> ((N-1)*M*C,)``:
+        the dense per-node blocks, node-major, in ``jacobian_indices()``
+        order (``opty/direct_collocation.py:2692-2887``)."""
+        from .utils import _MatrixFunction
+        from .codegen.lower import forward_jacobian
+        dag, table, con, nvec, nconst, chain = self._multi_arg_dag()
+        jac = forward_jacobian(dag, con, [table[s] for s in self._wrt()],
+                               chain)
+        C = len(self._wrt())
+        f = _MatrixFunction(dag, [node for row in jac for node in row], nvec,
+                            range(nvec, nvec + nconst), nvec + nconst,
+                            (self.num_eom, C), self.tmp_dir,
+                            self.show_compile_output, self._device)
+        result = np.empty((self.num_collocation_nodes - 1, self.num_eom*C))
+
+        def constraints_jacobian(state_values, specified_values,
+                                 parameter_values, interval_value):
+            args = self._multi_arg_values(state_values, specified_values,
+                                          parameter_values, interval_value)
+            return f(result, *args).ravel()
+
+        self._multi_arg_con_jac_func = constraints_jacobian
+
     def _host_free(self, free):
         free = np.ascontiguousarray(free, dtype=np.float64)
         if free.shape != (self.num_free,):

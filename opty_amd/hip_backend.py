@@ -124,6 +124,12 @@ class _Desc(ctypes.Structure):
             'con_waves_per_wg', 'layout')]
 
 
+class _MatDesc(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        'num_vec', 'num_const', 'rows', 'cols', 'wgs_per_block',
+        'waves_per_wg', 'num_uniform', 'device')]
+
+
 class _ObjDesc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int64), ('n', ctypes.c_int32),
                 ('q', ctypes.c_int32), ('r', ctypes.c_int32),
@@ -171,6 +177,13 @@ _SIGNATURES = {
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
     'opty_hip_host_register': (ctypes.c_int, [_P, ctypes.c_size_t]),
     'opty_hip_host_unregister': (ctypes.c_int, [_P]),
+    'opty_hip_matrix_create': (ctypes.c_int, [ctypes.POINTER(_MatDesc),
+                                              ctypes.c_char_p,
+                                              ctypes.POINTER(_P)]),
+    'opty_hip_matrix_destroy': (ctypes.c_int, [_P]),
+    'opty_hip_matrix_set_stream': (ctypes.c_int, [_P, _P]),
+    'opty_hip_matrix_eval': (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int64,
+                                            ctypes.c_int32]),
     'opty_hip_objective_create': (ctypes.c_int, [ctypes.POINTER(_ObjDesc),
                                                  ctypes.c_char_p,
                                                  ctypes.POINTER(_P)]),
@@ -386,6 +399,39 @@ class HipProblem(object):
             self._h, what, _ptr(free), _ptr(con), _ptr(jac), iters,
             ctypes.byref(ms)))
         return ms.value
+
+
+class HipMatrix(object):
+    """One ``opty_hip_matrix`` handle: a matrix of expressions evaluated for
+    n argument rows (the ``ufuncify_matrix`` call shape)."""
+
+    def __init__(self, desc, hsaco_path):
+        self._lib = load_library()
+        if self._lib.opty_hip_device_count() == 0:
+            raise HipBackendError('no HIP device is visible: the HIP '
+                                  'backend has no CPU fallback')
+        self._h = _P()
+        d = _MatDesc(**desc)
+        _check(self._lib.opty_hip_matrix_create(
+            ctypes.byref(d), hsaco_path.encode(), ctypes.byref(self._h)))
+        self.desc = dict(desc)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.opty_hip_matrix_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib.opty_hip_matrix_set_stream(self._h, stream_ptr))
+
+    def evaluate(self, result, vec_args, const_args, n, mem):
+        ptrs = (ctypes.c_void_p*max(1, len(vec_args)))(
+            *[_ptr(v) for v in vec_args])
+        cst = np.ascontiguousarray(const_args, dtype=np.float64)
+        _check(self._lib.opty_hip_matrix_eval(
+            self._h, _ptr(result), ctypes.addressof(ptrs), _ptr(cst), n, mem))
 
 
 class HipObjective(object):

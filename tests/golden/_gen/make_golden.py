@@ -152,7 +152,64 @@ def run_problem_facade():
                 num_constraints=prob.num_constraints)
 
 
+def run_ufuncify():
+    """The reference's own ``test_ufuncify_matrix`` case
+    (``opty/tests/test_utils.py:244-336``: a 2 x 2 matrix of transcendental
+    expressions over symbols named ``a``, ``b``, ``if`` / ``I`` / ``i``,
+    n = 10 000) on deterministic inputs, evaluated by the reference's
+    ``ufuncify_matrix`` with ``c`` as a vector argument and as ``const``."""
+    from opty.utils import ufuncify_matrix
+    a, b, c, I, i = sm.symbols('a, b, if, I, i')
+    mat = sm.Matrix([[a**2*sm.cos(sm.pi*b)**c, sm.tan(b)/sm.sin(a + b) + c**4],
+                     [a**2 + b**2 - sm.sqrt(c),
+                      ((a + b + c)*(a + b))/a*sm.sin(b)]])
+    n = 10000
+    # (0, 1) like the reference's np.random.random; c > 10 to stay real
+    a_vals = 0.5*(problems.make_free(n, seed=21) + 1.0) + 2.0**-21
+    b_vals = 0.5*(problems.make_free(n, seed=22) + 1.0) + 2.0**-21
+    c_vals = 0.5*(problems.make_free(n, seed=23) + 1.0) + 10.0
+    c_val = float(c_vals[17])
+    out = {}
+    f = ufuncify_matrix((a, b, c), mat)
+    out['vec'] = f(np.empty((n, 4)), a_vals, b_vals, c_vals).copy()
+    f = ufuncify_matrix((a, b, c), mat, const=(c,))
+    out['const'] = f(np.empty((n, 4)), a_vals, b_vals, c_val).copy()
+    # the variants below compile different C (OpenMP flags, symbol order in
+    # cse): equal to the last bits, not bit for bit
+    same = dict(rtol=1e-14, atol=0.0)
+    f = ufuncify_matrix((a, b, c), mat, const=(c,), parallel=True)
+    np.testing.assert_allclose(f(np.empty((n, 4)), a_vals, b_vals, c_val),
+                               out['const'], **same)
+    for other in (I, i):
+        f = ufuncify_matrix((a, b, other), mat.xreplace({c: other}))
+        np.testing.assert_allclose(
+            f(np.empty((n, 4)), a_vals, b_vals, c_vals), out['vec'], **same)
+    # cse pair input (opty/utils.py:677-682)
+    f = ufuncify_matrix((a, b, c), sm.cse(mat))
+    np.testing.assert_allclose(f(np.empty((n, 4)), a_vals, b_vals, c_vals),
+                               out['vec'], **same)
+    # inputs are a recipe (seeds above); outputs are kept for every 7th row
+    rows = np.unique(np.append(np.arange(0, n, 7), n - 1))
+    np.savez_compressed(os.path.join(OUT, 'ufuncify_matrix.npz'),
+                        rows=rows, seeds=np.array([21, 22, 23]),
+                        c_const=np.array([c_val]),
+                        a_rows=a_vals[rows], result_vec=out['vec'][rows],
+                        result_const=out['const'][rows])
+    return dict(kind='ufuncify', name='ufuncify_matrix', n=n,
+                sympy=sm.__version__,
+                reference='csu-hmc/opty v1.6.0.dev0 ufuncify_matrix '
+                          '(opty/utils.py:639)')
+
+
 def main():
+    if sys.argv[1:] == ['ufuncify_matrix']:
+        manifest_path = os.path.join(OUT, 'MANIFEST.json')
+        with open(manifest_path) as f:
+            manifest = json.load(f)
+        manifest['ufuncify_matrix'] = run_ufuncify()
+        with open(manifest_path, 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if sys.argv[1:] == ['problem_facade']:
         manifest_path = os.path.join(OUT, 'MANIFEST.json')
         with open(manifest_path) as f:
