@@ -48,6 +48,18 @@ UNI_WORKGROUPS = 16
 #: waves an MI355X holds at once when a CU takes four of these kernels' waves
 #: (256 CUs x 4 SIMDs; one wave per SIMD at their register footprint)
 RESIDENT_WAVES = 1024
+#: entries of a node's block one wave takes when registers do not ask for
+#: fewer (~50 KB of output per wave and 64-node block).  Interleaved A/B
+#: timings on MI355X after coefficient collection made the evaluation cheap
+#: (profiles/r02_strip_sweeps.txt): 10-link pendulum (P = 990) opty_jac
+#: 6/8/10/12 strips 0.1456/0.1446/0.1379/0.1394 ms, fused 6/8/9/10 strips
+#: 0.1460/0.1374/0.1359/0.1419 ms; 24-link (P = 5100) opty_jac gets faster up
+#: to the 32-strip cap (0.402 -> 0.375 ms)
+STRIP_ENTRIES = 110
+#: the fused kernel adds the constraint waves to every block; beyond about
+#: this many waves per block it loses again (24-link, 10 constraint waves:
+#: 20/24/32 strips 0.383/0.397/0.421 ms; 10-link: 12 strips 0.152 ms)
+FUSED_WAVES_PER_BLOCK = 30
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -328,6 +340,7 @@ class _ModuleWriter(object):
         self.o = opts
         self.dag = prog.dag
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
+        self._auto = None           # (G_live, G) of group_ranges()
 
     # -- leaves -------------------------------------------------------------
     def _is_vec_input(self, i):
@@ -407,16 +420,16 @@ class _ModuleWriter(object):
         return sum(1 for i in d.reachable(roots)
                    if d.op[i] not in (ir.CONST, ir.INPUT) and not d.uni[i])
 
-    def group_ranges(self):
-        """Assigns the P entries of the block to G waves.  The block is cut
+    def group_ranges(self, count=None):
+        """Assigns the P entries of the block to G waves (``count`` of them,
+        or the printer option ``groups``, or the automatic choice).  The block is cut
         into strips (contiguous entry ranges whose boundaries are multiples of
         a 16-double line, or of the chunk width for tiny blocks); a wave gets
         one strip, or -- ``interleave`` -- two: the cheapest remaining and the
         most expensive remaining one, so that every wave carries the same mix
         of store-only entries (structural zeros, constants) and evaluation
         work instead of half the waves only storing and half only computing.
-        With ``groups=None`` G is the smallest number for which every wave's
-        estimated live temporaries stay below ``max_live``.  Returns a list of
+        With ``groups=None`` G is ``auto_groups()[1]``.  Returns a list of
         groups, each a list of ``(e0, e1)`` strips in evaluation order."""
         P, K = self.p.P, self.o.chunk
         unit = 16 if self.line_mode() else K
@@ -455,25 +468,61 @@ class _ModuleWriter(object):
                 groups.append([cheap, dear] if g % 2 == 0 else [dear, cheap])
             return groups
 
-        if self.o.groups is not None:
-            return split(max(1, min(int(self.o.groups), nunits)))
-        leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
-        # at least one wave per 256 entries (2 KB of every node row) so that
-        # even an all-constant block yields enough waves to fill the chip
-        G = max(1, min(nunits, (P + 255)//256))
-        while True:
-            groups = split(G)
-            worst = max(
-                _max_live(self.dag,
-                          [[self.p.jac_out[v % P] for v in range(a, b)]
-                           for e0, e1 in grp
-                           for a, b in self._chunks(e0,
-                                                    self._virtual_end(e1))],
-                          leaf)
-                for grp in groups)
-            if worst <= self.o.max_live or G >= min(nunits, 32):
-                return groups
-            G += 1
+        if count is None and self.o.groups is not None:
+            count = int(self.o.groups)
+        if count is not None:
+            return split(max(1, min(int(count), nunits)))
+        if self._auto is None:
+            leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
+
+            def live(G):
+                return max(
+                    _max_live(self.dag,
+                              [[self.p.jac_out[v % P] for v in range(a, b)]
+                               for e0, e1 in grp
+                               for a, b in self._chunks(
+                                   e0, self._virtual_end(e1))],
+                              leaf)
+                    for grp in split(G))
+
+            # at least one wave per 256 entries (2 KB of every node row) so
+            # that even an all-constant block yields enough waves
+            first = max(1, min(nunits, (P + 255)//256))
+            top = min(nunits, 32)
+            # Registers: the fewest strips whose waves' estimated live
+            # temporaries stay below ``max_live`` -- or, for systems whose
+            # shared per-node values alone exceed that (a 24-link pendulum
+            # keeps ~235 alive however finely the block is cut), within 10 %
+            # of what the finest cut achieves: finer strips no longer help
+            # the registers then.
+            cand = sorted({g for g in list(range(first, 9)) +
+                           [10, 12, 16, 20, 24, top] if first <= g <= top})
+            budget = self.o.max_live
+            worst = {cand[0]: live(cand[0])}
+            if worst[cand[0]] > budget and len(cand) > 1:
+                worst[top] = live(top)
+                budget = max(budget, 1.1*worst[top])
+            G = cand[-1]
+            for g in cand:
+                if g not in worst:
+                    worst[g] = live(g)
+                if worst[g] <= budget:
+                    G = g
+                    break
+            fine = G
+            if self.line_mode():
+                fine = max(G, min(nunits, 32, -(-P//STRIP_ENTRIES)))
+            self._auto = (G, fine)
+        return split(self._auto[1])
+
+    def auto_groups(self):
+        """``(G_live, G)``: the fewest strips whose waves' estimated live
+        temporaries stay below ``max_live`` (registers), and the automatic
+        choice -- at least that, and about one wave per ``STRIP_ENTRIES``
+        entries (node-major line-mode blocks; at most 32)."""
+        if self._auto is None:
+            self.group_ranges()
+        return self._auto
 
     # -- kernels ---------------------------------------------------------------
     def _kernel_rows(self, groups, con_of_group):
@@ -848,8 +897,10 @@ class _ModuleWriter(object):
         return '\n'.join(src), dict(name='opty_inst', groups=1, lds_bytes=0)
 
 
-def _fit_one_round(auto_groups, con_waves, node_blocks):
-    """Strip count for a launch of ``node_blocks`` 64-node blocks.
+def _fit_one_round(auto_groups, con_waves, node_blocks, live_groups=None):
+    """Strip count for a launch of ``node_blocks`` 64-node blocks
+    (``auto_groups`` for large launches; never fewer than 60 % of
+    ``live_groups``, what the registers allow).
 
     A launch whose waves are all resident at once finishes in one round; one
     that needs 1.3 rounds takes almost as long as two.  Measured on MI355X
@@ -862,7 +913,8 @@ def _fit_one_round(auto_groups, con_waves, node_blocks):
     if not node_blocks or node_blocks*(auto_groups + con_waves) \
             <= RESIDENT_WAVES:
         return auto_groups
-    for g in range(auto_groups - 1, max(2, -(-3*auto_groups//5)) - 1, -1):
+    live = auto_groups if live_groups is None else live_groups
+    for g in range(auto_groups - 1, max(2, -(-3*live//5)) - 1, -1):
         if node_blocks*(g + con_waves) <= RESIDENT_WAVES:
             return g
     return auto_groups
@@ -923,20 +975,27 @@ def emit_module(prog, opts=None, node_blocks=None):
             if worst <= opts.max_live + 5 or len(con_sets) >= prog.M:
                 break
             parts += 1
-    if opts.groups is None and node_blocks:
-        fit = _fit_one_round(len(groups), len(con_sets), int(node_blocks))
-        if fit != len(groups):
-            import copy
-            opts = copy.copy(opts)
-            opts.groups = fit
-            w = _ModuleWriter(prog, opts)
-            groups = w.group_ranges()
+    fused_jac = groups
+    if opts.groups is None:
+        live, auto = w.auto_groups()
+        # the fused kernel carries the constraint waves as well
+        fused = max(live, min(auto, FUSED_WAVES_PER_BLOCK - len(con_sets)))
+        if node_blocks:
+            fit = _fit_one_round(auto, len(con_sets), int(node_blocks), live)
+            if fit != auto:
+                groups = w.group_ranges(fit)
+            fused = _fit_one_round(fused, len(con_sets), int(node_blocks),
+                                   live)
+        if fused != len(groups):
+            fused_jac = w.group_ranges(fused)
+        else:
+            fused_jac = groups
     con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
     # waves ride in the shadow of the store-bound Jacobian waves.
-    fused_groups = list(groups) + con_groups
-    con_of = [[] for _ in groups] + con_sets
+    fused_groups = list(fused_jac) + con_groups
+    con_of = [[] for _ in fused_jac] + con_sets
     parts = []
     kernels = {}
     for key, name, grp, cons, wpw in (
@@ -959,6 +1018,7 @@ def emit_module(prog, opts=None, node_blocks=None):
     source = '\n'.join(head + parts)
     meta = dict(kernels=kernels,
                 groups=[[list(rg) for rg in grp] for grp in groups],
+                fused_groups=[[list(rg) for rg in grp] for grp in fused_jac],
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
                 layout=getattr(prog, 'layout', 'coo'),
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),

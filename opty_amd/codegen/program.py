@@ -11,7 +11,24 @@ to ``ufuncify_matrix``.
 """
 
 from . import ir
+import os
+
 from .lower import Lowerer, forward_jacobian
+from .simplify import collect_coefficients
+
+
+def _collect(dag, con_out, jac):
+    """Coefficient collection (``simplify.py``) over the defect equations and
+    all their partials at once, so that sharing between them is seen.
+    ``OPTY_COLLECT=0`` turns it off (A/B measurements)."""
+    if os.environ.get('OPTY_COLLECT', '1') == '0':
+        return con_out, jac
+    width = len(jac[0]) if jac else 0
+    new = collect_coefficients(dag, list(con_out) +
+                               [node for row in jac for node in row])
+    M = len(con_out)
+    return new[:M], [new[M + j*width:M + (j + 1)*width]
+                     for j in range(len(jac))]
 
 
 class CollocationProgram(object):
@@ -106,6 +123,7 @@ def build_program(discrete_eom, state_cur, state_adj, traj_cur, traj_adj,
     con_out = [low.lower(e) for e in discrete_eom]
     wrt_nodes = [table[s] for s in wrt]
     jac = forward_jacobian(dag, con_out, wrt_nodes, chain)
+    con_out, jac = _collect(dag, con_out, jac)
     # (j, k) of every stored entry of the block, row-major.  The reference
     # stores all M*C of them, structural zeros included
     # (opty/direct_collocation.py:2589-2593); ``prune_zeros`` (opt-in, changes

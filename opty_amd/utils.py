@@ -61,6 +61,10 @@ class _MatrixFunction(object):
         self.vec_positions = tuple(k for k in range(num_args)
                                    if k not in self.const_positions)
         assert len(self.vec_positions) == num_vec
+        import os
+        if os.environ.get('OPTY_COLLECT', '1') != '0':
+            from .codegen.simplify import collect_coefficients
+            outputs = collect_coefficients(dag, list(outputs))
         prog = matrix_program(dag, outputs, num_vec,
                               len(self.const_positions), shape)
         self.source, self.meta = emit_matrix_module(prog, emit_options)

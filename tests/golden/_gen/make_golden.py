@@ -201,7 +201,40 @@ def run_ufuncify():
                           '(opty/utils.py:639)')
 
 
+def run_objective():
+    """Objective value and gradient of ``tests/objective_cases.py:
+    reference_cases`` from the reference's ``create_objective_function``
+    (``opty/utils.py:329-470``)."""
+    from opty.utils import create_objective_function
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import objective_cases
+    t, cases = objective_cases.reference_cases()
+    arrays = {}
+    for case in cases:
+        states, inputs, unknowns = case['args']
+        obj, grad = create_objective_function(
+            case['expr'], states, inputs, unknowns, case['N'], case['h'],
+            integration_method=case['method'], time_symbol=t)
+        free = problems.make_free(case['num_free'], seed=case['seed'])
+        arrays[case['name'] + '_value'] = np.array([obj(free)])
+        arrays[case['name'] + '_grad'] = np.asarray(grad(free), dtype=float)
+        print(case['name'], arrays[case['name'] + '_value'])
+    np.savez_compressed(os.path.join(OUT, 'objective.npz'), **arrays)
+    return dict(kind='objective', name='objective',
+                cases=[c['name'] for c in cases], sympy=sm.__version__,
+                reference='csu-hmc/opty v1.6.0.dev0 '
+                          'create_objective_function (opty/utils.py:329)')
+
+
 def main():
+    if sys.argv[1:] == ['objective']:
+        manifest_path = os.path.join(OUT, 'MANIFEST.json')
+        with open(manifest_path) as f:
+            manifest = json.load(f)
+        manifest['objective'] = run_objective()
+        with open(manifest_path, 'w') as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     if sys.argv[1:] == ['ufuncify_matrix']:
         manifest_path = os.path.join(OUT, 'MANIFEST.json')
         with open(manifest_path) as f:

@@ -69,3 +69,40 @@ def cases(N=20, seed=0):
         free=free[:-r], value=(xv[1:]**2).sum(),
         grad=np.hstack((0, 2*xv[1:], z(N*(n - 1 + q))))))
     return t, out
+
+
+def reference_cases():
+    """Problems whose objective value / gradient were recorded from the
+    reference's own ``create_objective_function``
+    (``opty/utils.py:329-470``) by ``tests/golden/_gen/make_golden.py
+    objective`` -> ``tests/golden/objective.npz``.  Inputs are the
+    deterministic ``problems.make_free`` recipe (seed per case)."""
+    t = sym.symbols('t')
+    x, v, u = [f(t) for f in sym.symbols('x, v, u', cls=sym.Function)]
+    f1, f2 = [f(t) for f in sym.symbols('f1:3', cls=sym.Function)]
+    m, c, k, p = sym.symbols('m, c, k, p')
+    allexpr = (sym.Integral(x**2 + m**2, t) + sym.Integral(c**2*f2**2, t) +
+               sym.sin(k)**2)
+    trig = sym.Integral(p*u**2 + sym.cos(x)*v**2, t) + 3*p**2
+    out = []
+    for method in ('backward euler', 'midpoint'):
+        tag = 'be' if method == 'backward euler' else 'mid'
+        out.append(dict(name='all_' + tag, expr=allexpr, method=method,
+                        N=20, h=0.3, seed=31,
+                        args=([x, v], [f2, f1], [m, c, k])))
+        out.append(dict(name='trig_' + tag, expr=trig, method=method,
+                        N=1001, h=0.01, seed=32, args=([x, v], [u], [p])))
+    # no unknown parameters: the swing-up's minimum-effort objective
+    out.append(dict(name='effort_be', expr=sym.Integral(u**2, t),
+                    method='backward euler', N=777, h=10.0/776, seed=33,
+                    args=([x, v], [u], [])))
+    out.append(dict(name='states_only_mid',
+                    expr=sym.Integral(sym.exp(-x)*v**2 + sym.sqrt(1 + x**2),
+                                      t),
+                    method='midpoint', N=130, h=0.05, seed=34,
+                    args=([x, v], [], [])))
+    for case in out:
+        states, inputs, unknowns = case['args']
+        case['num_free'] = (len(states) + len(inputs))*case['N'] + \
+            len(unknowns)
+    return t, out
