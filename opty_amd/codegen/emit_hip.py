@@ -905,7 +905,7 @@ def _fit_one_round(auto_groups, con_waves, node_blocks, live_groups=None):
     A launch whose waves are all resident at once finishes in one round; one
     that needs 1.3 rounds takes almost as long as two.  Measured on MI355X
     (10-link pendulum, 12 500 nodes = 196 blocks -- one of 8 node shards of
-    BASELINE config 4, profiles/r02_shard_strips.txt): 6 strips + 1
+    BASELINE config 4, profiles/r02_strip_sweeps.txt): 6 strips + 1
     constraint wave per block = 1372 waves, 0.0253 ms; 4 strips + 1 = 980
     waves <= 1024, 0.0233 ms.  Coarser strips cost registers (4 strips: 298
     VGPRs, still no scratch), so the count only goes down to 60 % of what the
