@@ -221,6 +221,25 @@ def other_configs(dev, iters):
             nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
             fused_algorithmic_bytes=nbytes,
             fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
+        if name == 'config2_pendulum':
+            # the cyipopt-callback path of the small config (NumPy in / out,
+            # PCIe and sync latency inclusive); the reference's compiled C
+            # takes 140 us + 189 us on one core
+            import numpy as np
+            hip.set_stream(None)
+            cf = col.generate_constraint_function()
+            jf = col.generate_jacobian_function()
+            hf = [problems.make_free(col.num_free, seed=s) for s in range(3)]
+            lat = {}
+            for label, fn in (('con', cf), ('jac', jf)):
+                fn(hf[0])
+                ts = []
+                for k in range(50):
+                    t0 = time.perf_counter()
+                    fn(hf[k % 3])
+                    ts.append(time.perf_counter() - t0)
+                lat[label] = 1e6*float(np.median(ts))
+            out[name]['host_path_us'] = lat
         hip.close()
         del con, jac, free
         torch.cuda.empty_cache()

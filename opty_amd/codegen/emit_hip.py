@@ -256,6 +256,10 @@ class _Body(object):
             e = 'fmin(%s, %s)' % (r(a[0]), r(a[1]))
         elif op == ir.ATAN2:
             e = 'atan2(%s, %s)' % (r(a[0]), r(a[1]))
+        elif op == ir.SELECT:
+            rel = {'lt': '<', 'le': '<=', 'eq': '==', 'ne': '!='}[a[0]]
+            e = '(%s %s %s ? %s : %s)' % (r(a[1]), rel, r(a[2]), r(a[3]),
+                                          r(a[4]))
         elif op in ('sin', 'cos'):
             other = 'cos' if op == 'sin' else 'sin'
             j = d._memo.get((other, a))

@@ -25,8 +25,11 @@ ADD, SUB, MUL, DIV, NEG = 'add', 'sub', 'mul', 'div', 'neg'
 POWI = 'powi'        # args: (a, n) with n a Python int >= 2
 POW = 'pow'          # args: (a, b)
 MAX, MIN, ATAN2 = 'max', 'min', 'atan2'
+SELECT = 'select'    # args: (rel, a, b, x, y): (a rel b) ? x : y
+RELATIONS = ('lt', 'le', 'eq', 'ne')
 UNARY = ('sqrt', 'sin', 'cos', 'tan', 'exp', 'log', 'abs', 'sign', 'asin',
-         'acos', 'atan', 'sinh', 'cosh', 'tanh', 'step')
+         'acos', 'atan', 'sinh', 'cosh', 'tanh', 'step', 'erf', 'erfc',
+         'floor', 'ceil', 'asinh', 'acosh', 'atanh')
 #: ``step(x)`` is 1 for x > 0 else 0 (used for d max / d min).
 
 #: kinds of INPUT nodes.  ``cur``/``adj`` are the per-node values of a
@@ -155,14 +158,14 @@ class DAG(object):
     def div(self, a, b):
         if self.is_const(b):
             v = self.value(b)
-            if self.is_const(a):
+            if self.is_const(a) and v != 0.0:
                 return self.const(self.value(a)/v)
             if v == 1.0:
                 return a
             if v == -1.0:
                 return self.neg(a)
             # x / c is kept as a true division (one correctly rounded op)
-        if a == self.zero:
+        if a == self.zero and b != self.zero:
             return self.zero
         if self.op[a] == NEG and self.op[b] == NEG:
             return self.div(self.args[a][0], self.args[b][0])
@@ -181,7 +184,10 @@ class DAG(object):
         if n < 0:
             return self.div(self.one, self.powi(a, -n))
         if self.is_const(a):
-            return self.const(self.value(a)**n)
+            try:
+                return self.const(self.value(a)**n)
+            except OverflowError:
+                pass
         if self.op[a] == NEG:
             p = self.powi(self.args[a][0], n)
             return p if n % 2 == 0 else self.neg(p)
@@ -197,7 +203,13 @@ class DAG(object):
             if v == -0.5:
                 return self.div(self.one, self.unary('sqrt', a))
             if self.is_const(a):
-                return self.const(math.pow(self.value(a), v))
+                # a fold that Python refuses (negative base with a
+                # fractional exponent, overflow) is left to the device,
+                # which returns what C's pow does (NaN / inf)
+                try:
+                    return self.const(math.pow(self.value(a), v))
+                except (ValueError, OverflowError, ZeroDivisionError):
+                    pass
         return self._node(POW, (a, b))
 
     _FOLD = {'sqrt': math.sqrt, 'sin': math.sin, 'cos': math.cos,
@@ -206,7 +218,10 @@ class DAG(object):
              'atan': math.atan, 'sinh': math.sinh, 'cosh': math.cosh,
              'tanh': math.tanh,
              'sign': lambda v: (v > 0) - (v < 0),
-             'step': lambda v: 1.0 if v > 0 else 0.0}
+             'step': lambda v: 1.0 if v > 0 else 0.0,
+             'erf': math.erf, 'erfc': math.erfc, 'floor': math.floor,
+             'ceil': math.ceil, 'asinh': math.asinh, 'acosh': math.acosh,
+             'atanh': math.atanh}
 
     def unary(self, name, a):
         assert name in UNARY, name
@@ -218,7 +233,7 @@ class DAG(object):
         if self.op[a] == NEG:
             x = self.args[a][0]
             if name in ('sin', 'tan', 'asin', 'atan', 'sinh', 'tanh',
-                        'sign'):
+                        'sign', 'erf', 'asinh', 'atanh'):
                 return self.neg(self.unary(name, x))
             if name in ('cos', 'cosh', 'abs'):
                 return self.unary(name, x)
@@ -232,6 +247,19 @@ class DAG(object):
         if name in (MAX, MIN) and a > b:
             a, b = b, a
         return self._node(name, (a, b))
+
+    _REL = {'lt': lambda a, b: a < b, 'le': lambda a, b: a <= b,
+            'eq': lambda a, b: a == b, 'ne': lambda a, b: a != b}
+
+    def select(self, rel, a, b, x, y):
+        """``(a rel b) ? x : y`` -- the branches of a Piecewise; both sides
+        are evaluated (straight-line code), one is kept."""
+        assert rel in RELATIONS, rel
+        if x == y:
+            return x
+        if self.is_const(a) and self.is_const(b):
+            return x if self._REL[rel](self.value(a), self.value(b)) else y
+        return self._node(SELECT, (rel, a, b, x, y))
 
     def sum(self, terms):
         """Balanced (pairwise) sum: short dependency chains, and the pairwise
@@ -267,6 +295,8 @@ class DAG(object):
             return ()
         if op == POWI:
             return (self.args[i][0],)
+        if op == SELECT:
+            return self.args[i][1:]
         return self.args[i]
 
     def reachable(self, roots):

@@ -20,8 +20,13 @@ _UNARY_FUNCS = {
     sm.sin: 'sin', sm.cos: 'cos', sm.tan: 'tan', sm.exp: 'exp',
     sm.log: 'log', sm.Abs: 'abs', sm.sign: 'sign', sm.asin: 'asin',
     sm.acos: 'acos', sm.atan: 'atan', sm.sinh: 'sinh', sm.cosh: 'cosh',
-    sm.tanh: 'tanh',
+    sm.tanh: 'tanh', sm.erf: 'erf', sm.erfc: 'erfc', sm.floor: 'floor',
+    sm.ceiling: 'ceil', sm.asinh: 'asinh', sm.acosh: 'acosh',
+    sm.atanh: 'atanh',
 }
+#: printed by the reference's C99 printer as 1/cos, 1/sin, cos/sin ...
+_RECIPROCAL_FUNCS = {sm.sec: 'cos', sm.csc: 'sin', sm.sech: 'cosh',
+                     sm.csch: 'sinh'}
 
 
 class Lowerer(object):
@@ -47,7 +52,8 @@ class Lowerer(object):
                 # function r_i(x_i) of an implicit known trajectory)
                 memo[e] = self.sym[e]
                 continue
-            if not ready and e.args and not e.is_Number:
+            if not ready and e.args and not e.is_Number and \
+                    not isinstance(e, sm.Piecewise):
                 stack.append((e, True))
                 for a in e.args:
                     if a not in memo:
@@ -107,8 +113,57 @@ class Lowerer(object):
             return acc
         if f is sm.Heaviside:
             return d.unary('step', m[e.args[0]])
+        if f in _RECIPROCAL_FUNCS:
+            return d.div(d.one, d.unary(_RECIPROCAL_FUNCS[f], m[e.args[0]]))
+        if f is sm.cot:
+            return d.div(d.unary('cos', m[e.args[0]]),
+                         d.unary('sin', m[e.args[0]]))
+        if f is sm.coth:
+            return d.div(d.unary('cosh', m[e.args[0]]),
+                         d.unary('sinh', m[e.args[0]]))
+        if f is sm.Mod:
+            # SymPy's Mod is the floored modulo: a - b*floor(a/b)
+            a, b = m[e.args[0]], m[e.args[1]]
+            return d.sub(a, d.mul(b, d.unary('floor', d.div(a, b))))
+        if isinstance(e, sm.Piecewise):
+            # ((e1, c1), (e2, c2), ...): the first true condition wins; no
+            # true condition is undefined (NaN, as the C printer's code)
+            acc = d.const(float('nan'))
+            for expr, cond in reversed(e.args):
+                acc = self._select(cond, self.lower(expr), acc)
+            return acc
         raise LoweringError('cannot lower %s (%s) to the HIP backend'
                             % (f, e))
+
+    def _select(self, cond, x, y):
+        """``cond ? x : y`` for a SymPy Boolean over relationals."""
+        d = self.dag
+        if cond is sm.true or cond is True:
+            return x
+        if cond is sm.false or cond is False:
+            return y
+        if isinstance(cond, sm.And):
+            acc = x
+            for c in reversed(cond.args):
+                acc = self._select(c, acc, y)
+            return acc
+        if isinstance(cond, sm.Or):
+            acc = y
+            for c in reversed(cond.args):
+                acc = self._select(c, x, acc)
+            return acc
+        if isinstance(cond, sm.Not):
+            return self._select(cond.args[0], y, x)
+        rels = {sm.Lt: ('lt', False), sm.Le: ('le', False),
+                sm.Gt: ('lt', True), sm.Ge: ('le', True),
+                sm.Eq: ('eq', False), sm.Ne: ('ne', False)}
+        for cls, (rel, swap) in rels.items():
+            if isinstance(cond, cls):
+                a, b = self.lower(cond.lhs), self.lower(cond.rhs)
+                if swap:
+                    a, b = b, a
+                return d.select(rel, a, b, x, y)
+        raise LoweringError('cannot lower the condition %s' % (cond,))
 
     def _pow(self, base, exp, exp_node=None):
         d = self.dag
@@ -163,7 +218,7 @@ def forward_jacobian(dag, outputs, wrt_inputs, chain=None):
                     g[col_of[wrt_node]] = dnode
         else:
             a = d.args[i]
-            ga = grad[a[0]]
+            ga = grad[a[0]] if op != ir.SELECT else None
             if op == ir.ADD:
                 g = combine(ga, grad[a[1]])
             elif op == ir.SUB:
@@ -208,6 +263,12 @@ def forward_jacobian(dag, outputs, wrt_inputs, chain=None):
                     wb = d.sub(d.one, wa)
                     g = combine(scaled(ga, wa) if ga else {},
                                 scaled(gb, wb) if gb else {})
+            elif op == ir.SELECT:
+                rel, ca, cb, x, y = a
+                gx, gy = grad[x], grad[y]
+                g = {k: d.select(rel, ca, cb, gx.get(k, zero),
+                                 gy.get(k, zero))
+                     for k in set(gx) | set(gy)}
             elif op == ir.ATAN2:
                 gb = grad[a[1]]
                 if not ga and not gb:
@@ -235,8 +296,22 @@ def forward_jacobian(dag, outputs, wrt_inputs, chain=None):
                     f = d.div(d.const(0.5), i)
                 elif op == 'abs':
                     f = d.unary('sign', x)
-                elif op in ('sign', 'step'):
+                elif op in ('sign', 'step', 'floor', 'ceil'):
                     f = zero
+                elif op == 'erf':       # 2/sqrt(pi) exp(-x^2)
+                    f = d.mul(d.const(1.1283791670955126),
+                              d.unary('exp', d.neg(d.mul(x, x))))
+                elif op == 'erfc':
+                    f = d.mul(d.const(-1.1283791670955126),
+                              d.unary('exp', d.neg(d.mul(x, x))))
+                elif op == 'asinh':
+                    f = d.div(d.one, d.unary('sqrt', d.add(d.mul(x, x),
+                                                           d.one)))
+                elif op == 'acosh':
+                    f = d.div(d.one, d.unary('sqrt', d.sub(d.mul(x, x),
+                                                           d.one)))
+                elif op == 'atanh':
+                    f = d.div(d.one, d.sub(d.one, d.mul(x, x)))
                 elif op == 'asin':
                     f = d.div(d.one, d.unary('sqrt', d.sub(d.one,
                                                           d.mul(x, x))))

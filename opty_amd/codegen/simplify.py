@@ -129,6 +129,8 @@ def collect_coefficients(dag, roots):
                 new = dag.pow(rewrite(a[0]), rewrite(a[1]))
             elif o in (ir.MAX, ir.MIN, ir.ATAN2):
                 new = dag.binary(o, rewrite(a[0]), rewrite(a[1]))
+            elif o == ir.SELECT:
+                new = dag.select(a[0], *[rewrite(k) for k in a[1:]])
             else:
                 new = dag.unary(o, rewrite(a[0]))
         memo[i] = new

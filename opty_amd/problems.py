@@ -244,6 +244,41 @@ def elementary_functions(num_nodes=45, method='backward euler',
                 integration_method=method)
 
 
+def piecewise_functions(num_nodes=53, method='backward euler'):
+    """Not from the reference's examples: a 3-state system with the
+    branching and special functions SymPy's C99 printer also accepts in
+    ``ufuncify_matrix`` (``opty/utils.py:748-757``) -- ``Piecewise`` with
+    relational / And / Or conditions (dry friction, a dead band, a one-sided
+    spring), ``erf``, ``asinh``, ``Abs``, ``Max`` -- with an
+    unknown input and an unknown parameter.  (``sec`` / ``cot`` / ``floor``
+    are lowered too, but the reference cannot build them: its symbol renaming
+    turns ``(1.0/cos(x))`` into ``(1.0/cos(x))_``, and SymPy's derivative of
+    ``floor`` is not printable -- so no fixture can pin those.)"""
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    mu, kk = sm.symbols('mu, kk', real=True)
+    x, v, z, u = me.dynamicsymbols('x, v, z, u', real=True)
+    friction = sm.Piecewise((mu*v, v > 0), (2*mu*v, True))
+    band = sm.Piecewise((0, sm.And(x > -sm.Rational(1, 4),
+                                   x < sm.Rational(1, 4))),
+                        (x - sm.Rational(1, 4), x >= sm.Rational(1, 4)),
+                        (x + sm.Rational(1, 4), True))
+    stop = sm.Piecewise((kk*(z - sm.Rational(1, 2))**2,
+                         sm.Or(z > sm.Rational(1, 2), v < -sm.Rational(3, 4))),
+                        (0, True))
+    eom = sm.Matrix([
+        x.diff() - v,
+        v.diff() + friction + kk*band + stop - u + sm.erf(x*z),
+        z.diff() - (sm.asinh(v) - sm.tanh(3*x)/4 + 1/sm.cos(z/2) -
+                    sm.cos(1 + x**2)/sm.sin(1 + x**2) +
+                    sm.Max(x, z)*sm.Abs(v)),
+    ])
+    return dict(equations_of_motion=eom, state_symbols=(x, v, z),
+                num_collocation_nodes=num_nodes, node_time_interval=0.04,
+                known_parameter_map={mu: 0.3}, time_symbol=t,
+                integration_method=method)
+
+
 def delay_equation(num_nodes=51, method='backward euler'):
     """Six chained delay segments with six algebraic path constraints
     (M = 12 equations for n = 6 states), six unknown inputs and twelve
@@ -333,6 +368,9 @@ CONFIGS = {
     'elementary_mid_small': (elementary_functions,
                              {'num_nodes': 70, 'method': 'midpoint',
                               'variable_duration': True}),
+    'piecewise_be_small': (piecewise_functions, {}),
+    'piecewise_mid_small': (piecewise_functions, {'num_nodes': 68,
+                                                  'method': 'midpoint'}),
     'config5_standin_24link': (n_link_cart_pendulum,
                                {'num_links': 24, 'num_nodes': 50000,
                                 'variable_duration': True}),

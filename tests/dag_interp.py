@@ -12,7 +12,17 @@ _UN = {'sqrt': np.sqrt, 'sin': np.sin, 'cos': np.cos, 'tan': np.tan,
        'exp': np.exp, 'log': np.log, 'abs': np.abs, 'sign': np.sign,
        'asin': np.arcsin, 'acos': np.arccos, 'atan': np.arctan,
        'sinh': np.sinh, 'cosh': np.cosh, 'tanh': np.tanh,
-       'step': lambda x: (x > 0).astype(float)}
+       'step': lambda x: (x > 0).astype(float),
+       'floor': np.floor, 'ceil': np.ceil, 'asinh': np.arcsinh,
+       'acosh': np.arccosh, 'atanh': np.arctanh}
+try:
+    from scipy.special import erf as _erf, erfc as _erfc
+    _UN.update(erf=_erf, erfc=_erfc)
+except ImportError:                     # pragma: no cover
+    import math
+    _UN.update(erf=np.vectorize(math.erf), erfc=np.vectorize(math.erfc))
+_REL = {'lt': np.less, 'le': np.less_equal, 'eq': np.equal,
+        'ne': np.not_equal}
 
 
 def evaluate(dag, roots, inputs):
@@ -44,8 +54,11 @@ def evaluate(dag, roots, inputs):
             v = np.minimum(val[a[0]], val[a[1]])
         elif op == ir.ATAN2:
             v = np.arctan2(val[a[0]], val[a[1]])
+        elif op == ir.SELECT:
+            v = np.where(_REL[a[0]](val[a[1]], val[a[2]]), val[a[3]],
+                         val[a[4]])
         else:
-            v = _UN[op](val[a[0]])
+            v = _UN[op](np.asarray(val[a[0]], dtype=float))
         val[i] = v
     return [val[r] for r in roots]
 
@@ -59,7 +72,13 @@ _DUN = {'sqrt': lambda x, f: 0.5/f, 'sin': lambda x, f: np.cos(x),
         'acos': lambda x, f: 1.0/np.sqrt(1.0 - x*x),
         'atan': lambda x, f: 1.0/(1.0 + x*x), 'sinh': lambda x, f: np.cosh(x),
         'cosh': lambda x, f: np.sinh(x), 'tanh': lambda x, f: 1.0 - f*f,
-        'step': lambda x, f: 0.0}
+        'step': lambda x, f: 0.0, 'floor': lambda x, f: 0.0,
+        'ceil': lambda x, f: 0.0,
+        'erf': lambda x, f: 1.1283791670955126*np.exp(-x*x),
+        'erfc': lambda x, f: 1.1283791670955126*np.exp(-x*x),
+        'asinh': lambda x, f: 1.0/np.sqrt(x*x + 1.0),
+        'acosh': lambda x, f: 1.0/np.sqrt(x*x - 1.0),
+        'atanh': lambda x, f: 1.0/(1.0 - x*x)}
 
 
 def evaluate_with_error_bound(dag, roots, inputs):
@@ -111,15 +130,19 @@ def evaluate_with_error_bound(dag, roots, inputs):
                 v = np.arctan2(y, x)
                 r2 = x*x + y*y
                 e = (np.abs(x)*err[a[0]] + np.abs(y)*err[a[1]])/r2
+            elif op == ir.SELECT:
+                c = _REL[a[0]](val[a[1]], val[a[2]])
+                v = np.where(c, val[a[3]], val[a[4]])
+                e = np.where(c, err[a[3]], err[a[4]])
             else:
-                x = val[a[0]]
+                x = np.asarray(val[a[0]], dtype=float)
                 v = _UN[op](x)
                 e = np.abs(_DUN[op](x, v))*err[a[0]]
             val[i] = v
             # one rounding of the operation's own result (2 for libm calls)
             err[i] = e + np.abs(v)*(2.0 if op in _UN or op in (
-                ir.POW, ir.ATAN2) else (0.0 if op in (ir.CONST, ir.INPUT,
-                                                      ir.NEG) else 1.0))
+                ir.POW, ir.ATAN2) else (0.0 if op in (
+                    ir.CONST, ir.INPUT, ir.NEG, ir.SELECT) else 1.0))
     return [val[r] for r in roots], [err[r] for r in roots]
 
 
