@@ -83,7 +83,14 @@ class SharedHostVector(object):
         self._pinned = False
         multi = dist.is_available() and dist.is_initialized()
         if rank == owner:
-            self.array = np.memmap(self.path, dtype=np.float64, mode='w+',
+            # reserve the pages now: a full /dev/shm raises here (ENOSPC)
+            # instead of a SIGBUS at the first write
+            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+            try:
+                os.posix_fallocate(fd, 0, max(8, 8*self.count))
+            finally:
+                os.close(fd)
+            self.array = np.memmap(self.path, dtype=np.float64, mode='r+',
                                    shape=(self.count,))
         if multi:
             dist.barrier(group)

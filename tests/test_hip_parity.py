@@ -532,19 +532,22 @@ def test_golden_window_embedded_at_full_size(name, N, layout):
                                 bound=bjac[:, sel[rs[j]:rs[j + 1]]])
 
 
-@pytest.mark.parametrize('name', ['config3_10link_small',
-                                  'elementary_mid_small',
-                                  'config5_standin_24link_small'])
-def test_optimisation_levels_agree(name, monkeypatch):
+@pytest.mark.parametrize('name,layout', [
+    ('config3_10link_small', 'coo'), ('elementary_mid_small', 'coo'),
+    ('config5_standin_24link_small', 'coo'),
+    ('config5_standin_24link_small', 'csr')])
+def test_optimisation_levels_agree(name, layout, monkeypatch):
     """The same generated module built by hipcc at -O1 and at the default
     level goes through different compiler pipelines and must agree to
-    rounding (a -O3 build of a 24-link kernel once did not: DESIGN.md 4.6)."""
+    rounding (a -O3 build of the 24-link row-sorted kernels once did not:
+    hip_backend.compile_module, tools/o3_repro.py)."""
     import opty_amd
     out = {}
     for lvl in (None, '-O1'):
         if lvl:
             monkeypatch.setenv('OPTY_HIPCC_OPT', lvl)
-        col = opty_amd.ConstraintCollocator(**problems.build(name))
+        col = opty_amd.ConstraintCollocator(jacobian_layout=layout,
+                                            **problems.build(name))
         free = problems.make_free(col.num_free, seed=11,
                                   variable_duration=col._variable_duration)
         out[lvl] = (col.generate_constraint_function()(free).copy(),

@@ -28,9 +28,18 @@ NAME = 'o3_repro_24link_csr_row47'
 
 
 def main():
-    levels = sys.argv[1:] or ['-O2', '-O3']
-    with lzma.open(os.path.join(HERE, NAME + '.hip.xz'), 'rt') as f:
-        source = f.read()
+    args = sys.argv[1:]
+    full = None
+    if args and args[0] == '--source':      # the whole module it came from
+        full = args[1]
+        args = args[2:]
+    levels = args or ['-O2', '-O3']
+    if full:
+        with open(full) as f:
+            source = f.read()
+    else:
+        with lzma.open(os.path.join(HERE, NAME + '.hip.xz'), 'rt') as f:
+            source = f.read()
     with open(os.path.join(HERE, NAME + '.json')) as f:
         info = json.load(f)
     desc, row = info['desc'], info['row']
