@@ -30,15 +30,19 @@ def _free_port():
     return port
 
 
-def test_ranges_written_in_place_equal_the_whole_evaluation():
-    """Three unequal node ranges, each written straight into the global
+@pytest.mark.parametrize('name', ['pend3_link_midpoint_small',
+                                  'pend2_link_vardur_unkmass_small'])
+def test_ranges_written_in_place_equal_the_whole_evaluation(name):
+    """(Backward Euler and midpoint; fixed parameters, and unknown parameters
+    + variable duration, whose node-invariant table is refilled from the
+    tail of the global ``free`` before every launch.)  Three unequal node ranges, each written straight into the global
     equation-major / node-major vectors (con_stride = N - 1), give bit for bit
     what one whole-problem launch of the same handle gives; a dense
     (M x nodes) block of one range equals the same slice."""
     import torch
     import opty_amd
     from opty_amd import hip_backend as hb
-    factory, fkw = problems.CONFIGS['pend3_link_midpoint_small']
+    factory, fkw = problems.CONFIGS[name]
     kw = factory(**dict(fkw, num_nodes=301))
     col = opty_amd.ConstraintCollocator(**kw)
     hip = col.hip
@@ -46,7 +50,9 @@ def test_ranges_written_in_place_equal_the_whole_evaluation():
     hip.set_stream(torch.cuda.current_stream().cuda_stream)
     prog = col._build_program()
     M, P, ncn = prog.M, prog.P, col.num_collocation_nodes - 1
-    free = torch.from_numpy(problems.make_free(col.num_free, seed=4)).to(dev)
+    free = torch.from_numpy(problems.make_free(
+        col.num_free, seed=4,
+        variable_duration=col._variable_duration)).to(dev)
     con = torch.empty(M*ncn, dtype=torch.float64, device=dev)
     jac = torch.empty(P*ncn, dtype=torch.float64, device=dev)
     hip.eval_con_jac(free, con, jac, hb.DEVICE)
