@@ -377,6 +377,66 @@ def test_problem_facade_matches_reference():
         prob.solve(free)
 
 
+def test_problem_solve_plumbing_with_a_stand_in_cyipopt(monkeypatch):
+    """``Problem.solve`` / ``add_option`` (``opty/direct_collocation.py:
+    242-247, 298-315``): ``cyipopt`` is absent here, so a stand-in module that
+    records how it is constructed and drives every callback once checks the
+    hand-over -- sizes, bound arrays, the callback object, triplet structure
+    consistent with the values, return value passed through."""
+    import sys
+    import types
+    import sympy as sm
+    import opty_amd
+    calls = {}
+
+    class FakeProblem(object):
+        def __init__(self, n, m, problem_obj=None, lb=None, ub=None, cl=None,
+                     cu=None):
+            calls['init'] = dict(n=n, m=m, obj=problem_obj, lb=lb, ub=ub,
+                                 cl=cl, cu=cu)
+            self.obj = problem_obj
+            self.options = {}
+
+        def add_option(self, key, value):
+            self.options[key] = value
+
+        def solve(self, x, lagrange=[], zl=[], zu=[]):
+            o = self.obj
+            rows, cols = o.jacobianstructure()
+            g = o.constraints(x)
+            vals = o.jacobian(x)
+            assert len(vals) == len(rows) == len(cols)
+            assert rows.max() < len(g) and cols.max() < len(x)
+            o.intermediate(0, 0, o.objective(x), 0, 0, 0, 0, 0, 0, 0, 0)
+            return x - 0.5*o.gradient(x), {'status': 0, 'g': g,
+                                           'options': dict(self.options)}
+
+    monkeypatch.setitem(sys.modules, 'cyipopt',
+                        types.SimpleNamespace(Problem=FakeProblem))
+    kw = problems.pendulum_swing_up(num_nodes=31)
+    T = [f for f in kw['equations_of_motion'].atoms(sm.Function)
+         if f.func.__name__ == 'T'][0]
+    N = kw['num_collocation_nodes']
+    obj, grad = opty_amd.create_objective_function(
+        sm.Integral(T**2, kw['time_symbol']), kw['state_symbols'], (T,), (),
+        N,
+        kw['node_time_interval'], integration_method='midpoint',
+        time_symbol=kw['time_symbol'])
+    prob = opty_amd.Problem(obj, grad, bounds={T: (-2.0, 2.0)}, **kw)
+    prob.add_option('max_iter', 7)
+    free = problems.make_free(prob.num_free, seed=8)
+    sol, info = prob.solve(free, respect_bounds=True)
+    init = calls['init']
+    assert (init['n'], init['m']) == (prob.num_free, prob.num_constraints)
+    assert init['obj'] is prob
+    np.testing.assert_array_equal(init['lb'], prob.lower_bound)
+    np.testing.assert_array_equal(init['cu'], prob._upp_con_bounds)
+    assert info['options'] == {'max_iter': 7}
+    np.testing.assert_allclose(sol, free - 0.5*np.asarray(grad(free)))
+    np.testing.assert_allclose(info['g'], prob.con(free))
+    assert prob.obj_value == [obj(free)]
+
+
 @pytest.mark.parametrize('name', ['config3_10link_small',
                                   'pend3_link_midpoint_small',
                                   'chaplygin_mid_small',
