@@ -436,7 +436,8 @@ def main():
                 con_host = SharedHostVector(
                     'opty_bench_con_%d' % os.getppid(), M*ncn, rank)
                 jac_host = SharedHostVector(
-                    'opty_bench_jac_%d' % os.getppid(), P*ncn, rank)
+                    'opty_bench_jac_%d' % os.getppid(), P*ncn, rank,
+                    pin=(a*P, b*P))     # the slice this rank writes
 
                 def host_step(k):
                     sh.evaluate(frees[k % 4])

@@ -836,6 +836,12 @@ class Problem(object):
     work without IPOPT.  ``solve`` needs ``cyipopt``.  Extra keywords
     ``device``, ``prune_zeros`` and ``jacobian_layout`` go to the collocator;
     ``jacobianstructure()`` always matches what ``jacobian(free)`` returns.
+
+    ``prune_zeros=True`` is the recommended setting when IPOPT runs on the
+    host: the callbacks move the Jacobian values over PCIe on every call
+    (14.4 ms for the 792 MB of the 10-link pendulum at N = 100 000, 100x the
+    kernel), the structure only once, and IPOPT does not need the structural
+    zeros the reference hands over (38.6 M instead of 99.0 M values: 5.9 ms).
     """
 
     INF = 10e19

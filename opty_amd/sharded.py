@@ -73,7 +73,9 @@ class SharedHostVector(object):
     process that runs IPOPT reads.
 
     ``torch_view(lo, hi)`` is a CPU tensor over ``[lo, hi)`` for
-    ``copy_(device_tensor, non_blocking=True)``.
+    ``copy_(device_tensor, non_blocking=True)``.  ``pin``: True page-locks
+    the whole vector in this process, ``(lo, hi)`` only that element range
+    (the part this rank writes; rounded out to whole pages), False nothing.
     """
 
     def __init__(self, name, count, rank, group=None, owner=0, pin=True):
@@ -101,9 +103,15 @@ class SharedHostVector(object):
             dist.barrier(group)
         if rank == owner:
             os.unlink(self.path)        # the mappings keep the memory alive
+        self._pin_view = None
         if pin:
             from . import hip_backend as hb
-            hb.host_register(self.array)
+            lo, hi = (0, self.count) if pin is True else pin
+            per_page = 4096//8
+            lo = (int(lo)//per_page)*per_page
+            hi = min(self.count, -(-int(hi)//per_page)*per_page)
+            self._pin_view = self.array[lo:hi]
+            hb.host_register(self._pin_view)
             self._pinned = True
 
     def torch_view(self, lo=0, hi=None):
@@ -114,7 +122,7 @@ class SharedHostVector(object):
     def close(self):
         if self._pinned:
             from . import hip_backend as hb
-            hb.host_unregister(self.array)
+            hb.host_unregister(self._pin_view)
             self._pinned = False
 
     def __del__(self):
