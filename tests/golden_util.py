@@ -43,8 +43,19 @@ def error_bounds(col, free, nodes=None):
     return dag_interp.error_bounds(col, free, nodes)
 
 
+def row_caps(jac_blocks):
+    """Per-entry cap on the tolerance floor from the reference values
+    themselves: ``max |entry|`` over the entry's equation row of its node's
+    block -- the magnitude of the 1/h terms of that equation at that node.
+    ``jac_blocks``: ``(nodes, M, C)``.  Returns ``(con_cap (M, nodes),
+    jac_cap (nodes, M, C))``."""
+    rowmax = np.abs(jac_blocks).max(axis=2)                  # (nodes, M)
+    return rowmax.T.copy(), np.repeat(rowmax[:, :, None],
+                                      jac_blocks.shape[2], axis=2)
+
+
 def assert_close(actual, desired, rtol=1e-10, scale=None, what='',
-                 bound=None):
+                 bound=None, cap=None):
     """Per-entry parity check, ``|a - d| <= max(rtol*|d|, floor)``.
 
     The bar is 1e-10 *relative* (BASELINE.json north_star).  An entry that is
@@ -59,6 +70,11 @@ def assert_close(actual, desired, rtol=1e-10, scale=None, what='',
       the entry's own terms justify;
     * ``scale`` (checksums over all nodes): floor = ``rtol*scale``;
     * neither: ``rtol * max|desired|`` (array-wide, coarse).
+
+    ``cap`` (array like ``desired``, see :func:`row_caps`): the floor is never
+    allowed above ``rtol*cap`` -- whatever the error analysis says, an entry
+    is held at least to 1e-10 of the largest entry of its own equation row at
+    its own node.
     """
     actual = np.asarray(actual, dtype=float)
     desired = np.asarray(desired, dtype=float)
@@ -71,6 +87,10 @@ def assert_close(actual, desired, rtol=1e-10, scale=None, what='',
         if scale is None:
             scale = float(np.max(np.abs(desired))) if desired.size else 1.0
         floor = rtol*scale
+    if cap is not None:
+        cap = np.asarray(cap, dtype=float)
+        assert cap.shape == desired.shape, (what, cap.shape)
+        floor = np.minimum(floor, rtol*cap)
     tol = np.maximum(rtol*np.abs(desired), floor)
     err = np.abs(actual - desired)
     if desired.size:

@@ -39,10 +39,16 @@ def test_program_matches_reference(name):
         assert [str(s) for s in getattr(col, attr)] == meta[key], attr
     con, jac = dag_interp.evaluate_collocator(col, z['free'])
     cb, jb = gu.error_bounds(col, z['free'])
+    N1, M, C = meta['N'] - 1, meta['M'], meta['C']
+    ccap, jcap = gu.row_caps(z['jac'][:N1*M*C].reshape(N1, M, C))
+    ccap = np.concatenate((ccap.ravel(),
+                           np.full(len(z['con']) - N1*M, np.inf)))
+    jcap = np.concatenate((jcap.ravel(),
+                           np.full(len(z['jac']) - N1*M*C, np.inf)))
     gu.assert_close(con, z['con'], 1e-10, what=name + ' con (interp)',
-                    bound=cb)
+                    bound=cb, cap=ccap)
     gu.assert_close(jac, z['jac'], 1e-10, what=name + ' jac (interp)',
-                    bound=jb)
+                    bound=jb, cap=jcap)
     r, c = col._instance_constraints_jacobian_indices()
     if meta['nnz_inst']:
         np.testing.assert_array_equal(r, z['rows'][-meta['nnz_inst']:])

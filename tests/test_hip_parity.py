@@ -37,8 +37,18 @@ def test_golden_full(name):
     np.testing.assert_array_equal(rows, z['rows'])
     np.testing.assert_array_equal(cols, z['cols'])
     cb, jb = gu.error_bounds(col, z['free'])
-    gu.assert_close(con, z['con'], RTOL, what=name + ' con', bound=cb)
-    gu.assert_close(jac, z['jac'], RTOL, what=name + ' jac', bound=jb)
+    # the floor is capped at 1e-10 of the largest entry of the entry's own
+    # block row (instance tails: uncapped, their bound is their own size)
+    N1, M, C = meta['N'] - 1, meta['M'], meta['C']
+    ccap, jcap = gu.row_caps(z['jac'][:N1*M*C].reshape(N1, M, C))
+    inf = np.full(len(z['con']) - N1*M, np.inf)
+    ccap = np.concatenate((ccap.ravel(), inf))
+    jcap = np.concatenate((jcap.ravel(),
+                           np.full(len(z['jac']) - N1*M*C, np.inf)))
+    gu.assert_close(con, z['con'], RTOL, what=name + ' con', bound=cb,
+                    cap=ccap)
+    gu.assert_close(jac, z['jac'], RTOL, what=name + ' jac', bound=jb,
+                    cap=jcap)
 
 
 @pytest.mark.parametrize('name', gu.SAMPLED)
@@ -61,10 +71,12 @@ def test_golden_sampled(name):
     cb = con[:M*(N - 1)].reshape(M, N - 1)
     # per-entry floors from the entries' own rounding-error bounds
     cbn, jbn, icb, ijb = gu.error_bounds(col, free, nodes)
+    ccap, jcap = gu.row_caps(z['jac_nodes'].reshape(len(nodes), M, C))
     gu.assert_close(blk[nodes], z['jac_nodes'], RTOL,
-                    what=name + ' jac nodes', bound=jbn)
+                    what=name + ' jac nodes', bound=jbn,
+                    cap=jcap.reshape(len(nodes), P))
     gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL,
-                    what=name + ' con nodes', bound=cbn)
+                    what=name + ' con nodes', bound=cbn, cap=ccap)
     np.testing.assert_array_equal(
         rows[:P*(N - 1)].reshape(N - 1, P)[nodes], z['rows_nodes'])
     np.testing.assert_array_equal(
