@@ -48,18 +48,18 @@ UNI_WORKGROUPS = 16
 #: waves an MI355X holds at once when a CU takes four of these kernels' waves
 #: (256 CUs x 4 SIMDs; one wave per SIMD at their register footprint)
 RESIDENT_WAVES = 1024
-#: entries of a node's block one wave takes when registers do not ask for
-#: fewer (~50 KB of output per wave and 64-node block).  Interleaved A/B
-#: timings on MI355X after coefficient collection made the evaluation cheap
-#: (profiles/r02_strip_sweeps.txt): 10-link pendulum (P = 990) opty_jac
-#: 6/8/10/12 strips 0.1456/0.1446/0.1379/0.1394 ms, fused 6/8/9/10 strips
-#: 0.1460/0.1374/0.1359/0.1419 ms; 24-link (P = 5100) opty_jac gets faster up
-#: to the 32-strip cap (0.402 -> 0.375 ms)
-STRIP_ENTRIES = 110
-#: the fused kernel adds the constraint waves to every block; beyond about
-#: this many waves per block it loses again (24-link, 10 constraint waves:
-#: 20/24/32 strips 0.383/0.397/0.421 ms; 10-link: 12 strips 0.152 ms)
-FUSED_WAVES_PER_BLOCK = 30
+#: entries of a node's block one wave of opty_jac takes when registers do not
+#: ask for fewer (~50 KB of output per wave and 64-node block), at most 32
+#: waves.  Interleaved A/B timings on MI355X after coefficient collection made
+#: the evaluation cheap (profiles/r02_strip_sweeps.txt), best strip count of
+#: opty_jac for n-link pendulums: 8 links (P = 666) 8, 10 links (990) 10-12,
+#: 14 links (1830) 18, 24 links (5100) >= 32.
+STRIP_ENTRIES = 100
+#: The fused kernel shares every block with the constraint waves and wants
+#: fewer, wider strips the larger the block: best counts 6-7 / 9 / 10-12 / 20
+#: for P = 666 / 990 / 1830 / 5100, i.e. about 0.286 sqrt(P) (an empirical fit
+#: over that family; off by one strip costs 1-3 %, the r01 choice cost 7 %).
+FUSED_STRIPS_PER_SQRT_ENTRY = 0.286
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -81,7 +81,10 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0):
+                 interleave=0, pad=0):
+        # experiment: that many empty waves appended to every block of
+        # opty_jac (they fill the slab and exit)
+        self.pad = int(pad)
         # 1: every wave gets a cheap strip and an expensive strip of the
         # block (see _ModuleWriter.group_ranges); measured slower than one
         # contiguous strip per wave on MI355X (more address streams), kept
@@ -118,7 +121,8 @@ class EmitOptions(object):
                 'waves=%s store_aux=%d con_rows_per_wave=%d interleave=%d' % (
                     self.chunk, self.groups, self.max_live, self.ablate,
                     self.flush_unroll, self.waves, self.store_aux,
-                    self.con_rows_per_wave, self.interleave))
+                    self.con_rows_per_wave, self.interleave) +
+                (' pad=%d' % self.pad if self.pad else ''))
 
 
 def _lit(v):
@@ -983,7 +987,9 @@ def emit_module(prog, opts=None, node_blocks=None):
     if opts.groups is None:
         live, auto = w.auto_groups()
         # the fused kernel carries the constraint waves as well
-        fused = max(live, min(auto, FUSED_WAVES_PER_BLOCK - len(con_sets)))
+        fused = max(live, min(auto, int(round(
+            FUSED_STRIPS_PER_SQRT_ENTRY*prog.P**0.5)))) if w.line_mode() \
+            else auto
         if node_blocks:
             fit = _fit_one_round(auto, len(con_sets), int(node_blocks), live)
             if fit != auto:
@@ -1004,7 +1010,8 @@ def emit_module(prog, opts=None, node_blocks=None):
     kernels = {}
     for key, name, grp, cons, wpw in (
             ('con', 'opty_con', con_groups, con_sets, 1),
-            ('jac', 'opty_jac', groups, [[] for _ in groups], opts.waves),
+            ('jac', 'opty_jac', list(groups) + [[(0, 0)]]*opts.pad,
+             [[] for _ in range(len(groups) + opts.pad)], opts.waves),
             ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves)):
         src, meta = w.kernel(name, grp, cons, wpw)
         parts += [src, '']

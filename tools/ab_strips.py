@@ -31,6 +31,8 @@ def main():
     factory, fkw = problems.CONFIGS[workload]
     if os.environ.get('OPTY_TUNE_NODES'):
         fkw = dict(fkw, num_nodes=int(os.environ['OPTY_TUNE_NODES']))
+    if os.environ.get('OPTY_TUNE_LINKS'):
+        fkw = dict(fkw, num_links=int(os.environ['OPTY_TUNE_LINKS']))
     kw = factory(**fkw)
     rounds = int(os.environ.get('OPTY_AB_ROUNDS', 7))
     iters = int(os.environ.get('OPTY_AB_ITERS', 100))

@@ -26,6 +26,9 @@ def main():
         workload = args.pop(0)
     kw = problems.build(workload.replace('config3_10link', 'config3_10link_small')
                         if workload == 'config3_10link' else workload)
+    if os.environ.get('OPTY_TUNE_LINKS'):
+        factory, fkw = problems.CONFIGS['config3_10link_small']
+        kw = factory(**dict(fkw, num_links=int(os.environ['OPTY_TUNE_LINKS'])))
     layout = os.environ.get('OPTY_TUNE_LAYOUT', 'coo')
     prune = os.environ.get('OPTY_TUNE_PRUNE') == '1'
     with ThreadPoolExecutor(8) as pool:
