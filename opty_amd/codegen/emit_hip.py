@@ -971,16 +971,21 @@ def emit_module(prog, opts=None, node_blocks=None):
         con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
     else:
         # As few constraint waves as the register budget allows: every wave
-        # re-reads the slab and recomputes the shared sub-expressions, so one
-        # wave for all rows is fastest when it fits (10-link pendulum), while
-        # a 50-equation system needs ~4 rows per wave not to spill.
+        # re-reads the slab and recomputes the shared sub-expressions (the 24
+        # sincos of a 24-link system cost more than the rows themselves), so
+        # one wave for all rows is fastest when it fits (10-link pendulum).
+        # These waves run one per SIMD whatever they need, so their budget is
+        # the whole register file: 1.5 x max_live estimated temporaries is
+        # where spilling starts -- 24-link, 50 rows: 10/5/4/2 waves (estimates
+        # 123/174/227/532) take 0.102/0.071/0.101/0.290 ms
+        # (profiles/r02_strip_sweeps.txt).
         leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
         parts = 1
         while True:
             con_sets = row_sets(-(-prog.M//parts))
             worst = max(_max_live(prog.dag, [[prog.con_out[j]] for j in rs],
                                   leaf) for rs in con_sets)
-            if worst <= opts.max_live + 5 or len(con_sets) >= prog.M:
+            if worst <= 1.5*opts.max_live or len(con_sets) >= prog.M:
                 break
             parts += 1
     fused_jac = groups

@@ -114,3 +114,55 @@ def test_handles_release_their_device_memory():
     torch.cuda.synchronize()
     after = torch.cuda.mem_get_info()[0]
     assert before - after < 8 << 20, (before, after)
+
+
+def test_matrix_function_misuse_fails():
+    """``opty_hip_matrix_*``: bad descriptors, wrong code objects, empty
+    evaluations and null arguments return a status, never garbage."""
+    import ctypes
+    import sympy as sm
+    from opty_amd import hip_backend as hb, ufuncify_matrix
+    x, y = sm.symbols('x, y')
+    f = ufuncify_matrix((x, y), sm.Matrix([[x*y, sm.sin(x)]]), const=(y,))
+    good = dict(f.hip.desc)
+    lib = hb.load_library()
+    # a collocation module has no matrix geometry problem, but a matrix module
+    # lacks opty_con / opty_conjac: creating a *problem* from it must fail
+    import opty_amd
+    col = opty_amd.ConstraintCollocator(
+        **problems.build('config1_vyasarayani'))
+    src, meta = col.generate_source()
+    from opty_amd.codegen.emit_hip import emit_matrix_module
+    hsaco_matrix = hb.compile_module(f.source)
+    with pytest.raises(hb.HipBackendError, match='missing'):
+        hb.HipProblem(col._descriptor(meta), hsaco_matrix)
+    for bad in (dict(good, rows=0), dict(good, wgs_per_block=0),
+                dict(good, device=99), dict(good, num_vec=-1)):
+        with pytest.raises(hb.HipBackendError):
+            hb.HipMatrix(bad, hsaco_matrix)
+    with pytest.raises(hb.HipBackendError, match='hipModuleLoad'):
+        hb.HipMatrix(good, '/nonexistent.hsaco')
+    res = np.empty((4, 2))
+    xs = np.linspace(0.0, 1.0, 4)
+    with pytest.raises(hb.HipBackendError, match='at least one'):
+        f.hip.evaluate(res, [xs], [2.0], 0, hb.HOST)
+    with pytest.raises(hb.HipBackendError, match='memory kind'):
+        f.hip.evaluate(res, [xs], [2.0], 4, 5)
+    with pytest.raises(hb.HipBackendError, match='null'):
+        f.hip.evaluate(res, [None], [2.0], 4, hb.HOST)
+    assert lib.opty_hip_matrix_eval(None, None, None, None, 4, 0) != 0
+    # and the handle still works afterwards
+    out = f(res, xs, 2.0)
+    np.testing.assert_allclose(out[:, 0, 0], 2.0*xs, rtol=1e-15)
+    np.testing.assert_allclose(out[:, 0, 1], np.sin(xs), rtol=1e-14)
+
+
+def test_host_register_misuse_fails():
+    from opty_amd import hip_backend as hb
+    lib = hb.load_library()
+    assert lib.opty_hip_host_register(None, 8) != 0
+    a = np.zeros(1024)
+    assert lib.opty_hip_host_register(a.ctypes.data, 0) != 0
+    hb.host_register(a)
+    hb.host_unregister(a)
+    assert lib.opty_hip_host_unregister(None) == 0
