@@ -472,3 +472,35 @@ def test_objective_modules_build_for_gfx950(tmp_path):
         if source not in seen:
             seen.add(source)
             assert os.path.getsize(hb.compile_module(source, str(tmp_path)))
+
+
+def test_strip_count_rules():
+    """The launch geometry the printer picks (emit_hip.py: ``group_ranges``,
+    ``_fit_one_round``; measurements in profiles/r02_strip_sweeps.txt):
+    opty_jac about one wave per 100 entries, the fused kernel about
+    0.286 sqrt(P) strips, and a node shard that would need 1.x rounds gets the
+    coarser cut that fits the 1024 resident waves."""
+    from opty_amd.codegen.emit_hip import _fit_one_round, RESIDENT_WAVES
+    col = ConstraintCollocator(**problems.build('config3_10link_small'))
+    prog = col._build_program()
+
+    def waves(node_blocks):
+        k = emit_module(prog, EmitOptions(),
+                        node_blocks=node_blocks)[1]['kernels']
+        return k['jac']['groups'], k['conjac']['groups']
+
+    assert waves(None) == (10, 10)              # 10 strips; 9 strips + 1 con
+    assert waves(1563) == (10, 10)              # N = 100 000
+    assert waves(391) == (10, 10)               # 4 shards: several rounds
+    jac, fused = waves(196)                     # 8 shards: 12 500 nodes
+    assert 196*fused <= RESIDENT_WAVES < 196*10 and fused == 5
+    assert jac == 4
+    assert waves(1) == (10, 10)                 # tiny launches fit anyway
+    # explicit strip counts are never overridden
+    k = emit_module(prog, EmitOptions(groups=6), node_blocks=196)[1]
+    assert k['kernels']['jac']['groups'] == 6
+    # the rule itself
+    assert _fit_one_round(9, 1, 196, live_groups=5) == 4
+    assert _fit_one_round(9, 1, 1563, live_groups=5) == 9
+    assert _fit_one_round(9, 1, 100) == 9
+    assert _fit_one_round(32, 5, 100, live_groups=16) == 32   # nothing fits
