@@ -119,7 +119,6 @@ def test_handles_release_their_device_memory():
 def test_matrix_function_misuse_fails():
     """``opty_hip_matrix_*``: bad descriptors, wrong code objects, empty
     evaluations and null arguments return a status, never garbage."""
-    import ctypes
     import sympy as sm
     from opty_amd import hip_backend as hb, ufuncify_matrix
     x, y = sm.symbols('x, y')
@@ -132,7 +131,6 @@ def test_matrix_function_misuse_fails():
     col = opty_amd.ConstraintCollocator(
         **problems.build('config1_vyasarayani'))
     src, meta = col.generate_source()
-    from opty_amd.codegen.emit_hip import emit_matrix_module
     hsaco_matrix = hb.compile_module(f.source)
     with pytest.raises(hb.HipBackendError, match='missing'):
         hb.HipProblem(col._descriptor(meta), hsaco_matrix)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Developer tool (GPU box): the torch.distributed calls bench.py makes, on
 RCCL with however many ranks the launcher gives (1 on a 1-GPU box)."""
-import os, sys, time
+import os, sys
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 import torch
