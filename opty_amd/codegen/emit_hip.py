@@ -81,7 +81,10 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0, pad=0):
+                 interleave=0, pad=0, occupancy=0):
+        # experiment: ask the compiler for that many waves per SIMD
+        # (amdgpu_waves_per_eu: 2 caps the kernels at 256 VGPRs)
+        self.occupancy = int(occupancy)
         # experiment: that many empty waves appended to every block of
         # opty_jac (they fill the slab and exit)
         self.pad = int(pad)
@@ -122,7 +125,8 @@ class EmitOptions(object):
                     self.chunk, self.groups, self.max_live, self.ablate,
                     self.flush_unroll, self.waves, self.store_aux,
                     self.con_rows_per_wave, self.interleave) +
-                (' pad=%d' % self.pad if self.pad else ''))
+                (' pad=%d' % self.pad if self.pad else '') +
+                (' occupancy=%d' % self.occupancy if self.occupancy else ''))
 
 
 def _lit(v):
@@ -802,7 +806,10 @@ class _ModuleWriter(object):
                   if keep[g] else []
                   for g, grp in enumerate(groups)]
         lds_doubles = max(1, (len(rows) + W*ring_rows)*TS)
-        src = ['extern "C" __global__ void __launch_bounds__(%d)' % (64*W),
+        occ = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (
+            self.o.occupancy, self.o.occupancy) if self.o.occupancy else ''
+        src = ['extern "C" __global__ void __launch_bounds__(%d)%s'
+               % (64*W, occ),
                '%s(%s)' % (name, KERNEL_PARAMS), '{',
                '    __shared__ double lds[%d];' % lds_doubles,
                self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
@@ -928,6 +935,49 @@ def _fit_one_round(auto_groups, con_waves, node_blocks, live_groups=None):
     return auto_groups
 
 
+def _dual_occupancy_cut(prog, writer, opts, live_groups, con_waves,
+                        node_blocks):
+    """Launch geometry for SMALL launches: two waves per SIMD.
+
+    A node shard of BASELINE config 4 (12 500 nodes = 196 blocks) is too
+    short to amortise a wave's own critical path (slab fill, then its chunks
+    one after the other): with one wave per SIMD either every wave is long (4
+    strips: one round of 980 waves, 0.0221 ms on some boxes, 0.0260 ms on
+    others) or the launch takes two rounds (9 strips: 0.0239 ms).  With
+    16-entry chunks (16.6 KB ring tiles), four waves per workgroup sharing
+    one slab and the kernels capped at 256 VGPRs (amdgpu_waves_per_eu(2)) a CU
+    holds 8 waves, the chip 2048: 7 strips + 1 constraint wave = 2 full
+    workgroups per block, 1568 waves in ONE round of short waves --
+    0.0200-0.0202 ms where 4 strips took 0.0221, 0.0222 ms where they took
+    0.0260 (profiles/r02_strip_sweeps.txt).  It only pays when it makes the
+    launch fit: at 25 000 nodes it ties with the default, at 50 000+ it loses
+    (0.081 vs 0.072 ms), as it does at full size (r01: no gain).
+
+    Returns ``(options, strips)`` or None when it does not apply: the printer
+    options were set by hand, the launch fits one round as it is or does not
+    fit 2048 waves, the slab + four ring tiles exceed half a CU's LDS, or the
+    strips would be fewer than the register minimum."""
+    import copy
+    if (opts.chunk != 32 or opts.waves is not None or opts.occupancy or
+            not writer.line_mode() or not node_blocks):
+        return None
+    total = 4*((2*RESIDENT_WAVES//int(node_blocks))//4)   # waves per block
+    strips = total - con_waves
+    if strips < max(2, live_groups):
+        return None
+    strips = min(strips, writer.auto_groups()[1])
+    # whole workgroups only: a partly filled one still takes a slot of four
+    strips -= (strips + con_waves) % 4
+    if strips < max(2, live_groups):
+        return None
+    lds = (len(prog.rows) + 4*(16 + 16))*TS*8
+    if 2*lds > 160*1024:
+        return None
+    dual = copy.copy(opts)
+    dual.chunk, dual.waves, dual.occupancy = 16, 4, 2
+    return dual, strips
+
+
 def emit_matrix_module(prog, opts=None):
     """Module of a *matrix program* (``program.matrix_program``: a plain
     ``(rows x cols)`` matrix of expressions evaluated for ``n`` independent
@@ -995,7 +1045,16 @@ def emit_module(prog, opts=None, node_blocks=None):
         fused = max(live, min(auto, int(round(
             FUSED_STRIPS_PER_SQRT_ENTRY*prog.P**0.5)))) if w.line_mode() \
             else auto
-        if node_blocks:
+        dual = None
+        if node_blocks and int(node_blocks)*(fused + len(con_sets)) > \
+                RESIDENT_WAVES:
+            dual = _dual_occupancy_cut(prog, w, opts, live, len(con_sets),
+                                       int(node_blocks))
+        if dual is not None:
+            opts, fused = dual
+            w = _ModuleWriter(prog, opts)
+            groups = w.group_ranges(fused)
+        elif node_blocks:
             fit = _fit_one_round(auto, len(con_sets), int(node_blocks), live)
             if fit != auto:
                 groups = w.group_ranges(fit)

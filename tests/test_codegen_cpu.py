@@ -487,18 +487,29 @@ def test_strip_count_rules():
     def waves(node_blocks):
         k = emit_module(prog, EmitOptions(),
                         node_blocks=node_blocks)[1]['kernels']
-        return k['jac']['groups'], k['conjac']['groups']
+        return (k['jac']['groups'], k['conjac']['groups'],
+                k['conjac']['waves_per_wg'])
 
-    assert waves(None) == (10, 10)              # 10 strips; 9 strips + 1 con
-    assert waves(1563) == (10, 10)              # N = 100 000
-    assert waves(391) == (10, 10)               # 4 shards: several rounds
-    jac, fused = waves(196)                     # 8 shards: 12 500 nodes
-    assert 196*fused <= RESIDENT_WAVES < 196*10 and fused == 5
-    assert jac == 4
-    assert waves(1) == (10, 10)                 # tiny launches fit anyway
+    assert waves(None) == (10, 10, 1)           # 10 strips; 9 strips + 1 con
+    assert waves(1563) == (10, 10, 1)           # N = 100 000
+    assert waves(391) == (10, 10, 1)            # 4 shards: several rounds
+    # 8 shards (12 500 nodes): two waves per SIMD, 7 strips + 1 constraint
+    # wave = 2 workgroups of 4 waves per block, all 1568 waves resident
+    jac, fused, wpw = waves(196)
+    assert (jac, fused, wpw) == (7, 8, 4)
+    assert 196*fused <= 2*RESIDENT_WAVES
+    src = emit_module(prog, EmitOptions(), node_blocks=196)[0]
+    assert 'amdgpu_waves_per_eu(2, 2)' in src and 'chunk=16' in src
+    assert waves(1) == (10, 10, 1)              # tiny launches fit anyway
     # explicit strip counts are never overridden
     k = emit_module(prog, EmitOptions(groups=6), node_blocks=196)[1]
     assert k['kernels']['jac']['groups'] == 6
+    assert k['kernels']['jac']['waves_per_wg'] == 1
+    # hand-set printer options switch the small-launch geometry off; the
+    # coarser one-round cut at one wave per SIMD is what is left
+    k = emit_module(prog, EmitOptions(waves=1), node_blocks=196)[1]
+    assert (k['kernels']['jac']['groups'],
+            k['kernels']['conjac']['groups']) == (4, 5)
     # the rule itself
     assert _fit_one_round(9, 1, 196, live_groups=5) == 4
     assert _fit_one_round(9, 1, 1563, live_groups=5) == 9

@@ -90,6 +90,43 @@ def test_ranges_written_in_place_equal_the_whole_evaluation(name):
     hip.set_stream(None)
 
 
+@pytest.mark.parametrize('rank', [0, 3, 7])
+def test_one_of_eight_shards_against_the_reference(rank):
+    """A 12 500-node shard of config 4 (world size 8) runs the small-launch
+    geometry -- two waves per SIMD, 16-entry chunks, 4-wave workgroups
+    (``emit_hip._dual_occupancy_cut``): values at the reference's sampled
+    nodes that fall into the shard, indices of the shard."""
+    import torch
+    from opty_amd.sharded import ShardedCollocator
+    meta, z = gu.load('config3_10link')
+    N, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    sh = ShardedCollocator(rank=rank, world_size=8,
+                           **problems.build('config3_10link'))
+    km = sh.collocator.hip.desc
+    assert km['fused_waves_per_wg'] == 4       # the small-launch geometry
+    free = problems.make_free(sh.collocator.num_free, seed=meta['seed'])
+    con, jac = sh.evaluate(torch.from_numpy(free).cuda())
+    torch.cuda.synchronize()
+    con, jac = con.cpu().numpy(), jac.cpu().numpy().reshape(-1, P)
+    nodes = z['nodes']
+    pick = (nodes >= sh.a) & (nodes < sh.b)
+    assert pick.sum() >= 2
+    sel = nodes[pick]
+    cbn, jbn, _, _ = gu.error_bounds(sh.collocator, free, sel)
+    gu.assert_close(jac[sel - sh.a], z['jac_nodes'][pick], RTOL,
+                    what='1/8 shard jac nodes', bound=jbn)
+    gu.assert_close(con[:, sel - sh.a], z['con_nodes'][:, pick], RTOL,
+                    what='1/8 shard con nodes', bound=cbn)
+    # every value of the shard was written (no NaN / stale zero blocks)
+    assert np.isfinite(jac).all() and np.abs(jac).sum(axis=1).min() > 0
+    rows, cols = sh.jacobian_indices_local()
+    np.testing.assert_array_equal(
+        rows.reshape(-1, P)[sel - sh.a], z['rows_nodes'][pick])
+    np.testing.assert_array_equal(
+        cols.reshape(-1, P)[sel - sh.a], z['cols_nodes'][pick])
+
+
 def _worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
