@@ -25,7 +25,7 @@ from tune_jac import parse                                    # noqa: E402
 def main():
     args = sys.argv[1:]
     workload = 'config3_10link'
-    if args and '=' not in args[0] and args[0] != 'default':
+    if args and '=' not in args[0] and args[0] not in ('default', 'auto'):
         workload = args.pop(0)
     dev = torch.device('cuda:0')
     factory, fkw = problems.CONFIGS[workload]
