@@ -180,9 +180,11 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
 
 /* ---- node shards (one process per GPU) ----------------------
  * Evaluates the constraint nodes [node_begin, node_end) of the handle's
- * problem from the GLOBAL free vector (device memory; only the time-node
- * columns [node_begin, node_end] of its trajectory rows and its parameter tail
- * are read -- the one-node halo of opty/direct_collocation.py:2411-2413).
+ * problem from the GLOBAL free vector (device memory, full length; only the
+ * time-node columns [node_begin, node_end] of its trajectory rows and its
+ * parameter tail contribute -- the one-node halo of
+ * opty/direct_collocation.py:2411-2413; the last 64-node block may touch up
+ * to 64 columns past node_end, whose values are not used).
  * Device pointers only:
  *   con : the shard's value of equation j, node i goes to
  *         con[j*con_stride + (i - node_begin)]; con_stride = N-1 with
