@@ -26,7 +26,7 @@ from .codegen.program import build_program
 from .codegen.emit_hip import emit_module, EmitOptions
 from . import hip_backend as hb
 
-__all__ = ['Problem', 'ConstraintCollocator']
+__all__ = ['Problem', 'ConstraintCollocator', 'ShardedProblem']
 
 logger = logging.getLogger(__name__)
 
@@ -859,7 +859,7 @@ class Problem(object):
                              'of motion must be ordinary differential '
                              'equations (ODEs) or differential algebraic '
                              'equations (DAEs).')
-        self.collocator = ConstraintCollocator(
+        self.collocator = self._make_collocator(
             equations_of_motion, state_symbols, num_collocation_nodes,
             node_time_interval, known_parameter_map, known_trajectory_map,
             instance_constraints, time_symbol, tmp_dir, integration_method,
@@ -886,10 +886,8 @@ class Problem(object):
             raise ValueError('The gradient function can only have one or two'
                              ' arguments.')
         self.obj, self.obj_grad = obj, obj_grad
-        self.con = self.collocator.generate_constraint_function()
-        self.con_jac = self.collocator.generate_jacobian_function()
-        self.con_jac_rows, self.con_jac_cols = \
-            self.collocator.jacobian_indices()
+        (self.con, self.con_jac, self.con_jac_rows,
+         self.con_jac_cols) = self._make_callbacks()
         self.num_free = self.collocator.num_free
         self.num_constraints = self.collocator.num_constraints
         self._generate_bound_arrays()
@@ -899,6 +897,16 @@ class Problem(object):
 
     bounds = property(lambda self: self._bounds)
     eom_bounds = property(lambda self: self._eom_bounds)
+
+    # -- what a subclass replaces to evaluate elsewhere (ShardedProblem) ------
+    def _make_collocator(self, *args, **kwargs):
+        return ConstraintCollocator(*args, **kwargs)
+
+    def _make_callbacks(self):
+        """``(constraints, jacobian, rows, cols)``."""
+        rows, cols = self.collocator.jacobian_indices()
+        return (self.collocator.generate_constraint_function(),
+                self.collocator.generate_jacobian_function(), rows, cols)
 
     # -- bounds (opty/direct_collocation.py:370-440) -----------------------
     def _generate_constraint_bound_arrays(self):
@@ -1064,3 +1072,61 @@ class Problem(object):
         if respect_bounds:
             self.check_bounds_conflict(free)
         return self._ipopt().solve(free, lagrange=lagrange, zl=zl, zu=zu)
+
+
+class ShardedProblem(Problem):
+    """``Problem`` whose ``constraints`` / ``jacobian`` callbacks are evaluated
+    by all GPUs of a node (BASELINE config 4; one process per GPU,
+    ``torch.distributed`` initialised by the caller).
+
+    Every rank constructs it with the same arguments.  The rank that runs the
+    solver (``root``) uses it like a ``Problem`` (``solve``, or the callbacks
+    directly) and calls :meth:`shutdown` when done; every other rank calls
+    :meth:`serve`, which returns after the shutdown.  The collocation nodes are
+    sharded (:class:`opty_amd.sharded.ShardedCollocator`), each rank copies its
+    shard of every result over its own PCIe link into host vectors shared by
+    all processes (:class:`opty_amd.sharded.ShardedCallbacks`).  Instance
+    constraints and the CSR layout are not sharded.
+
+    Extra keywords: ``group`` (process group), ``root`` (solver rank),
+    ``torch_device`` (default ``cuda:<device>``).
+    """
+
+    def __init__(self, *args, group=None, root=0, torch_device=None,
+                 **kwargs):
+        self._group, self._root, self._torch_device = group, root, \
+            torch_device
+        super().__init__(*args, **kwargs)
+
+    def _make_collocator(self, eom, states, num_nodes, interval, par_map,
+                         traj_map, instance_constraints, time_symbol, tmp_dir,
+                         integration_method, parallel, **kwargs):
+        from .sharded import ShardedCollocator
+        device = self._torch_device
+        if device is None:
+            device = 'cuda:%d' % kwargs.get('device', 0)
+        kwargs.pop('device', None)
+        self.sharded = ShardedCollocator(
+            eom, states, num_nodes, interval, par_map, traj_map,
+            instance_constraints, group=self._group, device=device,
+            time_symbol=time_symbol, tmp_dir=tmp_dir,
+            integration_method=integration_method, parallel=parallel,
+            **kwargs)
+        return self.sharded.collocator
+
+    def _make_callbacks(self):
+        from .sharded import ShardedCallbacks
+        self.callbacks = ShardedCallbacks(self.sharded, root=self._root)
+        rows = cols = None
+        if self.callbacks.is_root:       # the structure goes to the solver
+            rows, cols = self.collocator.jacobian_indices()
+        return (self.callbacks.constraints, self.callbacks.jacobian, rows,
+                cols)
+
+    def serve(self):
+        """Non-root ranks: evaluate on the root's command until shutdown."""
+        self.callbacks.serve()
+
+    def shutdown(self):
+        """Root: release the serving ranks."""
+        self.callbacks.shutdown()

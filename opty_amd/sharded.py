@@ -38,7 +38,7 @@ import os
 import numpy as np
 
 __all__ = ['partition_nodes', 'slab_of', 'ShardedCollocator',
-           'SharedHostVector']
+           'SharedHostVector', 'ShardedCallbacks']
 
 
 def partition_nodes(num_constraint_nodes, world_size):
@@ -235,7 +235,7 @@ class ShardedCollocator(object):
                 jac[self.a*self.P:self.b*self.P])
 
     # -- evaluation (no collective) ----------------------------------------------
-    def _hip_evaluate(self, free, con2d, jac1d, a, b):
+    def _hip_evaluate(self, free, con2d, jac1d, a, b, what='both'):
         import torch
         from . import hip_backend as hb
         # the kernels run on torch's current stream, so that the exchange and
@@ -244,12 +244,15 @@ class ShardedCollocator(object):
         if stream != self._stream:
             self.collocator.hip.set_stream(stream)
             self._stream = stream
+        sel = {'both': hb.EVAL_FUSED, 'con': hb.EVAL_CON, 'jac': hb.EVAL_JAC}
         self.collocator.hip.eval_shard(
-            hb.EVAL_FUSED, free, con2d, con2d.stride(0), jac1d, a, b)
+            sel[what], free, con2d if what != 'jac' else None,
+            con2d.stride(0), jac1d if what != 'con' else None, a, b)
 
-    def evaluate(self, free, in_place=False):
-        """Constraints and Jacobian of this rank's nodes from the global
-        ``free`` tensor (on this rank's device).  Returns ``(con, jac)``:
+    def evaluate(self, free, in_place=False, what='both'):
+        """Constraints and Jacobian (``what``: ``'both'``, ``'con'`` or
+        ``'jac'``) of this rank's nodes from the global ``free`` tensor (on
+        this rank's device).  Returns ``(con, jac)``:
         ``con`` is ``(M, b - a)`` (row ``j`` = equation ``j``), ``jac`` the
         slice ``[a*P, b*P)`` of the global value vector.  ``in_place``: write
         the shard directly into this rank's copy of the global vectors (what
@@ -259,7 +262,10 @@ class ShardedCollocator(object):
                 self._num_free(), free.numel()))
         con, jac = self._own_views() if in_place else \
             (self.con_local, self.jac_local)
-        self._evaluate(free, con, jac, self.a, self.b)
+        if what == 'both':
+            self._evaluate(free, con, jac, self.a, self.b)
+        else:
+            self._evaluate(free, con, jac, self.a, self.b, what)
         self._in_place = bool(in_place)
         return con, jac
 
@@ -345,12 +351,16 @@ class ShardedCollocator(object):
 
     def to_host(self, con_host, jac_host):
         """Copies this rank's shard into the node-wide host vectors
-        (:class:`SharedHostVector` of ``M*(N-1)`` and ``P*(N-1)`` doubles) over
-        this rank's own PCIe link; asynchronous on the current stream."""
+        (:class:`SharedHostVector` of ``M*(N-1)`` and ``P*(N-1)`` doubles; None
+        skips one) over this rank's own PCIe link; asynchronous on the current
+        stream."""
         con, jac = (self._own_views() if self._in_place
                     else (self.con_local, self.jac_local))
-        jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
-            jac, non_blocking=True)
+        if jac_host is not None:
+            jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
+                jac, non_blocking=True)
+        if con_host is None:
+            return
         ncn = self.N - 1
         dst = con_host.torch_view().view(self.M, ncn)[:, self.a:self.b]
         if self._in_place:
@@ -396,3 +406,110 @@ class ShardedCollocator(object):
         cols = np.empty(count, dtype=np.int64)
         hip.jacobian_indices_range(self.a, self.b, rows, cols, hb.HOST)
         return rows, cols
+
+
+class ShardedCallbacks(object):
+    """``constraints(free)`` / ``jacobian(free)`` for a host-side NLP solver,
+    served by all ranks of a node-sharded problem.
+
+    The solver (IPOPT) runs in ONE process, rank ``root``; the other ranks
+    call :meth:`serve` and wait.  A callback on the root writes ``free`` into a
+    page-locked host vector shared by all processes and broadcasts a command;
+    every rank then loads ``free`` over its own PCIe link, evaluates its node
+    range and copies its shard straight into the shared, page-locked output
+    vectors -- the host-visible rate scales with the number of PCIe links
+    instead of funnelling the 792 MB Jacobian of BASELINE config 4 through one
+    (``to_host``).  Layouts are the reference's
+    (``opty/direct_collocation.py:2446``, ``:2885-2887``): ``constraints``
+    returns a fresh array, ``jacobian`` the persistent shared buffer.
+    """
+
+    _STOP, _CON, _JAC, _BOTH = 0, 1, 2, 3
+
+    def __init__(self, sharded, name=None, root=0, pin=True):
+        import torch
+        import torch.distributed as dist
+        sh = self.sh = sharded
+        self.root = root
+        self.is_root = sh.rank == root
+        name = name or 'opty_cb_%d' % os.getppid()
+        ncn = sh.N - 1
+        nfree = sh._num_free()
+        gpu = sh.device.type == 'cuda'
+        pin = bool(pin and gpu)
+        self.free_host = SharedHostVector(name + '_free', nfree, sh.rank,
+                                          sh.group, root, pin)
+        self.con_host = SharedHostVector(name + '_con', sh.M*ncn, sh.rank,
+                                         sh.group, root, pin)
+        self.jac_host = SharedHostVector(
+            name + '_jac', sh.P*ncn, sh.rank, sh.group, root,
+            (sh.a*sh.P, sh.b*sh.P) if pin else False)
+        self.free_dev = torch.empty(nfree, dtype=torch.float64,
+                                    device=sh.device)
+        # the command travels by broadcast; gloo moves host memory
+        on_dev = gpu and dist.get_backend(sh.group) != 'gloo'
+        self._cmd = torch.zeros(1, dtype=torch.int64,
+                                device=sh.device if on_dev else 'cpu')
+        self._dist = dist
+
+    # -- one evaluation, on every rank ------------------------------------------
+    def _round(self, cmd):
+        what = {self._CON: 'con', self._JAC: 'jac', self._BOTH: 'both'}[cmd]
+        self.free_dev.copy_(self.free_host.torch_view(), non_blocking=True)
+        self.sh.evaluate(self.free_dev, what=what)
+        self.sh.to_host(self.con_host if what != 'jac' else None,
+                        self.jac_host if what != 'con' else None)
+        if self.sh.device.type == 'cuda':
+            import torch
+            torch.cuda.synchronize(self.sh.device)
+        self._dist.barrier(self.sh.group)      # every shard has landed
+
+    def _command(self, cmd):
+        self._cmd.fill_(cmd)
+        self._dist.broadcast(self._cmd, self.root, group=self.sh.group)
+        return int(self._cmd.item())
+
+    # -- the solver's side (rank `root`) -------------------------------------------
+    def _call(self, free, cmd):
+        assert self.is_root, 'callbacks run on the root rank; others serve()'
+        free = np.asarray(free, dtype=np.float64)
+        if free.shape != (self.free_host.count,):
+            raise ValueError('free must have shape ({},), got {}'.format(
+                self.free_host.count, free.shape))
+        self.free_host.array[:] = free
+        self._command(cmd)
+        self._round(cmd)
+
+    def constraints(self, free):
+        self._call(free, self._CON)
+        return np.array(self.con_host.array)        # fresh, as :2444
+
+    def jacobian(self, free):
+        self._call(free, self._JAC)
+        return self.jac_host.array                   # persistent, as :2814
+
+    def constraints_and_jacobian(self, free):
+        self._call(free, self._BOTH)
+        return np.array(self.con_host.array), self.jac_host.array
+
+    def shutdown(self):
+        """Releases the serving ranks (root only; idempotent)."""
+        if self.is_root and self._cmd is not None:
+            self._command(self._STOP)
+        self.close()
+
+    # -- the other ranks ---------------------------------------------------------------
+    def serve(self):
+        """Evaluates on command until the root shuts the service down."""
+        assert not self.is_root
+        while True:
+            cmd = self._command(0)
+            if cmd == self._STOP:
+                break
+            self._round(cmd)
+        self.close()
+
+    def close(self):
+        self._cmd = None
+        for v in (self.free_host, self.con_host, self.jac_host):
+            v.close()

@@ -36,10 +36,13 @@ class _OracleShard(object):
         self.num_free_global = self.o.num_free + self.rows*(self.N -
                                                             (b - a + 1))
 
-    def __call__(self, free, con2d, jac1d, a, b):
+    def __call__(self, free, con2d, jac1d, a, b, what='both'):
         slab = slab_of(free.numpy(), self.N, self.rows, a, b)
-        con2d.copy_(torch.from_numpy(self.con(slab).reshape(self.o.M, b - a)))
-        jac1d.copy_(torch.from_numpy(np.asarray(self.jac(slab))))
+        if what != 'jac':
+            con2d.copy_(torch.from_numpy(
+                self.con(slab).reshape(self.o.M, b - a)))
+        if what != 'con':
+            jac1d.copy_(torch.from_numpy(np.asarray(self.jac(slab))))
 
 
 def _free_port():
@@ -124,6 +127,64 @@ def test_shards_reassemble_to_full(tmp_path, name, N, world):
         assert ('g_con' in z[r].files) == (r == world - 1)
     np.testing.assert_allclose(z[world - 1]['g_con'], c_ref, **kw)
     np.testing.assert_allclose(z[world - 1]['g_jac'], j_ref, **kw)
+
+
+def _callback_worker(rank, world, port, name, N, out):
+    from opty_amd.sharded import ShardedCallbacks
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        factory, fkw = problems.CONFIGS[name]
+        kw = factory(**dict(fkw, num_nodes=N))
+        a, b = partition_nodes(N - 1, world)[rank]
+        ev = _OracleShard(kw, a, b)
+        sh = ShardedCollocator(evaluator=ev, block_shape=(ev.o.M,
+                                                          ev.o.M*ev.o.C),
+                               **kw)
+        sh.set_num_free(ev.num_free_global)
+        cb = ShardedCallbacks(sh, name='opty_t_cb_%d' % port, root=1)
+        if rank != 1:
+            cb.serve()                  # returns after the root's shutdown
+            return
+        frees = [problems.make_free(ev.num_free_global, seed=s,
+                                    variable_duration=ev.o.variable_duration)
+                 for s in (1, 2, 3)]
+        c1 = cb.constraints(frees[0])
+        j1 = cb.jacobian(frees[0]).copy()
+        c2 = cb.constraints(frees[1])               # line search: con only
+        c3, j3 = cb.constraints_and_jacobian(frees[2])
+        with pytest.raises(ValueError):
+            cb.constraints(frees[0][:-1])
+        np.savez(out, f1=frees[0], f2=frees[1], f3=frees[2], c1=c1, j1=j1,
+                 c2=c2, c3=c3, j3=j3.copy())
+        cb.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,N,world', [
+    ('msd_be_small', 24, 2), ('pend2_link_vardur_unkmass_small', 26, 3)])
+def test_callbacks_served_by_all_ranks(tmp_path, name, N, world):
+    """``ShardedCallbacks``: the solver's rank (here rank 1) gets
+    ``constraints(free)`` / ``jacobian(free)`` of the whole problem through
+    the shared host vectors while the other ranks serve."""
+    from oracle.collocation_oracle import OracleCollocator
+    out = str(tmp_path/'root.npz')
+    mp.spawn(_callback_worker, args=(world, _free_port(), name, N, out),
+             nprocs=world, join=True)
+    z = np.load(out)
+    factory, fkw = problems.CONFIGS[name]
+    full = OracleCollocator(name='shard', **factory(**dict(fkw,
+                                                           num_nodes=N)))
+    con, jac = (full.generate_constraint_function(),
+                full.generate_jacobian_function())
+    kw = dict(rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(z['c1'], con(z['f1']), **kw)
+    np.testing.assert_allclose(z['j1'], jac(z['f1']), **kw)
+    np.testing.assert_allclose(z['c2'], con(z['f2']), **kw)
+    np.testing.assert_allclose(z['c3'], con(z['f3']), **kw)
+    np.testing.assert_allclose(z['j3'], jac(z['f3']), **kw)
 
 
 def test_partition():

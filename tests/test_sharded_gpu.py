@@ -234,3 +234,86 @@ def test_bench_strong_scaling_two_ranks():
     assert res['config']['nodes_per_launch'] == 50000
     assert set(res['config']['variants']) == {'gather', 'to_host'}
     assert res['value'] > 0 and res['roofline']['frac'] > 0
+
+
+def _problem_worker(rank, world, port, out):
+    import sys
+    import types
+    import torch
+    import torch.distributed as dist
+    import sympy as sm
+    import opty_amd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        factory, fkw = problems.CONFIGS['pend3_link_midpoint_small']
+        kw = factory(**dict(fkw, num_nodes=3002))
+        F = [f for f in kw['equations_of_motion'].atoms(sm.Function)
+             if f.func.__name__ == 'F'][0]
+        N = kw['num_collocation_nodes']
+        obj, grad = opty_amd.create_objective_function(
+            sm.Integral(F**2, kw['time_symbol']), kw['state_symbols'], (F,),
+            (), N, kw['node_time_interval'], integration_method='midpoint',
+            time_symbol=kw['time_symbol'])
+        prob = opty_amd.ShardedProblem(obj, grad, bounds={F: (-50.0, 50.0)},
+                                       **kw)
+        if rank != 0:
+            prob.serve()
+            return
+
+        class FakeProblem(object):          # stands in for cyipopt.Problem
+            def __init__(self, n, m, problem_obj=None, lb=None, ub=None,
+                         cl=None, cu=None):
+                self.o, self.m = problem_obj, m
+
+            def solve(self, x, lagrange=[], zl=[], zu=[]):
+                g = self.o.constraints(x)
+                vals = np.array(self.o.jacobian(x))
+                rows, cols = self.o.jacobianstructure()
+                assert len(g) == self.m and len(vals) == len(rows)
+                return x, {'g': g, 'jac': vals, 'obj': self.o.objective(x)}
+
+        sys.modules['cyipopt'] = types.SimpleNamespace(Problem=FakeProblem)
+        frees = [problems.make_free(prob.num_free, seed=s) for s in (5, 6)]
+        _, info = prob.solve(frees[0])
+        c2 = prob.constraints(frees[1])           # a second, different point
+        rows, cols = prob.jacobianstructure()
+        np.savez(out, f0=frees[0], f1=frees[1], g=info['g'], jac=info['jac'],
+                 c2=c2, rows=rows, cols=cols, obj=np.array([info['obj']]),
+                 ab=np.array([prob.sharded.a, prob.sharded.b]))
+        prob.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_problem_callbacks_from_two_ranks(tmp_path):
+    """``opty_amd.ShardedProblem``: rank 0 drives a (stand-in) IPOPT whose
+    callbacks are evaluated by both ranks through the shared page-locked host
+    vectors; compared with the single-GPU ``Problem`` on the same inputs."""
+    import sympy as sm
+    import torch.multiprocessing as mp
+    import opty_amd
+    out = str(tmp_path/'root.npz')
+    mp.spawn(_problem_worker, args=(2, _free_port(), out), nprocs=2,
+             join=True)
+    z = np.load(out)
+    assert tuple(z['ab']) == (0, 1501)              # 3001 nodes: 1501 + 1500
+    factory, fkw = problems.CONFIGS['pend3_link_midpoint_small']
+    kw = factory(**dict(fkw, num_nodes=3002))
+    col = opty_amd.ConstraintCollocator(**kw)
+    con, jac = (col.generate_constraint_function(),
+                col.generate_jacobian_function())
+    rows, cols = col.jacobian_indices()
+    np.testing.assert_array_equal(z['rows'], rows)
+    np.testing.assert_array_equal(z['cols'], cols)
+    cb, jb = gu.error_bounds(col, z['f0'])
+    gu.assert_close(z['g'], con(z['f0']), 1e-12, what='sharded problem con',
+                    bound=cb)
+    gu.assert_close(z['jac'], jac(z['f0']), 1e-12,
+                    what='sharded problem jac', bound=jb)
+    cb, _ = gu.error_bounds(col, z['f1'])
+    gu.assert_close(z['c2'], con(z['f1']), 1e-12,
+                    what='sharded problem con 2', bound=cb)
+    assert np.isfinite(z['obj'][0])
