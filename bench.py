@@ -204,7 +204,7 @@ def other_configs(dev, iters):
         col = opty_amd.ConstraintCollocator(device=dev.index,
                                             **problems.build(name))
         hip = col.hip
-        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        hip.use_torch_stream()
         free = torch.from_numpy(problems.make_free(
             col.num_free, variable_duration=col._variable_duration)).to(dev)
         con = torch.empty(col.num_constraints, dtype=torch.float64,
@@ -339,7 +339,7 @@ def main():
                            device=dev, **kw)
     col = sh.collocator
     hip = col.hip
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     a, b = sh.a, sh.b
     M, P, N = sh.M, sh.P, sh.N
     nfree = col.num_free

@@ -97,8 +97,13 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
                     opty_hip_problem **out);
 int opty_hip_destroy(opty_hip_problem *p);
 
-/* Use an existing hipStream_t (e.g. torch's current stream) for all work of
- * this handle; NULL restores the handle's own stream.  A handle's device
+/* The null / legacy default stream (hipStreamLegacy) as a set_stream argument:
+ * NULL itself means "the handle's own stream". */
+#define OPTY_HIP_STREAM_LEGACY ((void *)1)
+
+/* Use an existing hipStream_t (e.g. torch's current stream; pass
+ * OPTY_HIP_STREAM_LEGACY for the default stream, whose handle is NULL) for
+ * all work of this handle; NULL restores the handle's own stream.  A handle's device
  * state belongs to one stream at a time: work issued after a switch is
  * ordered behind everything the handle enqueued on the previous stream. */
 int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream);

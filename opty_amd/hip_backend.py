@@ -29,11 +29,26 @@ DEFAULT_CACHE = os.path.join(_PKG, '_cache')
 ARCH = 'gfx950'
 
 HOST, DEVICE = 0, 1
+#: hipStreamLegacy: the null / legacy default stream (torch's default)
+STREAM_LEGACY = 1
 EVAL_CON, EVAL_JAC, EVAL_PAIR, EVAL_FUSED = 0, 1, 2, 3
 
 
 class HipBackendError(RuntimeError):
     pass
+
+
+def torch_stream_pointer(stream=None):
+    """``hipStream_t`` of a ``torch.cuda.Stream`` (default: the current one)
+    for the ``set_stream`` calls.  torch's default stream is the legacy null
+    stream, whose handle is 0 -- which ``opty_hip_*_set_stream`` reads as
+    "back to the handle's own stream"; it is passed as ``hipStreamLegacy``
+    (``OPTY_HIP_STREAM_LEGACY``) instead, so that the kernels really are
+    ordered with the torch operations around them."""
+    import torch
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return stream.cuda_stream or STREAM_LEGACY
 
 
 def _hipcc():
@@ -323,6 +338,11 @@ class HipProblem(object):
     def set_stream(self, stream_ptr):
         _check(self._lib.opty_hip_set_stream(self._h, stream_ptr))
 
+    def use_torch_stream(self, stream=None):
+        """Run this handle's work on a torch stream (default: the current
+        one), ordered with the torch operations issued there."""
+        self.set_stream(torch_stream_pointer(stream))
+
     def synchronize(self):
         _check(self._lib.opty_hip_synchronize(self._h))
 
@@ -432,6 +452,11 @@ class HipMatrix(object):
     def set_stream(self, stream_ptr):
         _check(self._lib.opty_hip_matrix_set_stream(self._h, stream_ptr))
 
+    def use_torch_stream(self, stream=None):
+        """Run this handle's work on a torch stream (default: the current
+        one), ordered with the torch operations issued there."""
+        self.set_stream(torch_stream_pointer(stream))
+
     def evaluate(self, result, vec_args, const_args, n, mem):
         ptrs = (ctypes.c_void_p*max(1, len(vec_args)))(
             *[_ptr(v) for v in vec_args])
@@ -463,6 +488,11 @@ class HipObjective(object):
 
     def set_stream(self, stream_ptr):
         _check(self._lib.opty_hip_objective_set_stream(self._h, stream_ptr))
+
+    def use_torch_stream(self, stream=None):
+        """Run this handle's work on a torch stream (default: the current
+        one), ordered with the torch operations issued there."""
+        self.set_stream(torch_stream_pointer(stream))
 
     def evaluate(self, free, grad, mem):
         """Returns the objective value; fills ``grad`` when it is given."""

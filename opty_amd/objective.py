@@ -241,6 +241,8 @@ def create_objective_function(objective, state_symbols,
         if hasattr(free, 'data_ptr'):
             if tuple(free.shape) != (num_free,):
                 raise ValueError('free must have shape (%d,)' % num_free)
+            # ordered behind whatever produced the tensor on torch's stream
+            handle.use_torch_stream()
             return free, hb.DEVICE
         free = np.ascontiguousarray(free, dtype=np.float64)
         if free.shape != (num_free,):

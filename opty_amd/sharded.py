@@ -240,7 +240,8 @@ class ShardedCollocator(object):
         from . import hip_backend as hb
         # the kernels run on torch's current stream, so that the exchange and
         # the copies that follow (torch / RCCL ops) are ordered behind them
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = hb.torch_stream_pointer(
+            torch.cuda.current_stream(self.device))
         if stream != self._stream:
             self.collocator.hip.set_stream(stream)
             self._stream = stream

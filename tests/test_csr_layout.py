@@ -84,7 +84,7 @@ def test_csr_matches_coo_layout_ragged(N):
     con = torch.empty(csr.num_constraints, dtype=torch.float64, device=dev)
     jac = torch.full((hip.nnz,), float('nan'), dtype=torch.float64,
                      device=dev)
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     hip.eval_con_jac(f, con, jac, hb.DEVICE)
     torch.cuda.synchronize()
     assert np.abs(jac.cpu().numpy() - js).max() <= tol

@@ -154,7 +154,7 @@ def test_device_pointers_and_linearity():
     col = _collocator('config3_10link')
     hip = col.hip
     dev = torch.device('cuda:0')
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     free = problems.make_free(col.num_free, seed=3)
     rng = np.random.default_rng(0)
     direction = rng.standard_normal(col.num_free)
@@ -498,7 +498,7 @@ def test_unaligned_output_pointers():
     col = _collocator('config3_10link', num_nodes=1000)
     hip = col.hip
     dev = torch.device('cuda:0')
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     free = torch.from_numpy(problems.make_free(col.num_free, seed=8)).to(dev)
     ref = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
     hip.eval_jac(free, ref, hb.DEVICE)
@@ -643,7 +643,7 @@ def test_million_node_problem_device_windows():
     col = opty_amd.ConstraintCollocator(**factory(**dict(fkw, num_nodes=N)))
     hip = col.hip
     dev = torch.device('cuda', 0)
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     free = problems.make_free(col.num_free, seed=77)
     offsets = (0, 987654, N - n_small)
     for off in offsets:

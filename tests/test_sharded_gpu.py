@@ -48,7 +48,7 @@ def test_ranges_written_in_place_equal_the_whole_evaluation(name):
     col = opty_amd.ConstraintCollocator(**kw)
     hip = col.hip
     dev = torch.device('cuda:0')
-    hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    hip.use_torch_stream()
     prog = col._build_program()
     M, P, ncn = prog.M, prog.P, col.num_collocation_nodes - 1
     free = torch.from_numpy(problems.make_free(
@@ -139,8 +139,7 @@ def _worker(rank, world, port, out):
         torch.cuda.set_device(dev)
         kw = problems.build('config3_10link')
         sh = ShardedCollocator(device=dev, **kw)
-        sh.collocator.hip.set_stream(
-            torch.cuda.current_stream().cuda_stream)
+        sh.collocator.hip.use_torch_stream()
         meta, _ = gu.load('config3_10link')
         free = torch.from_numpy(problems.make_free(
             sh.collocator.num_free, seed=meta['seed'])).to(dev)

@@ -171,7 +171,7 @@ def test_ufuncify_matrix_argument_contract():
         ufuncify_matrix((x, y), mat, const=(k,))
     # device-resident call: CUDA tensors in, evaluated in place
     dev = torch.device('cuda:0')
-    f.hip.set_stream(torch.cuda.current_stream().cuda_stream)
+    f.hip.use_torch_stream()
     xt = torch.linspace(-1, 1, 777, dtype=torch.float64, device=dev)
     yt = torch.cos(xt)
     res = torch.empty((777, 9), dtype=torch.float64, device=dev)

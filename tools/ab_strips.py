@@ -41,7 +41,7 @@ def main():
         opts = None if spec == 'auto' else (
             EmitOptions() if spec == 'default' else parse(spec))
         col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
-        col.hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        col.hip.use_torch_stream()
         cols.append((spec, col))
     col = cols[0][1]
     free = torch.from_numpy(problems.make_free(

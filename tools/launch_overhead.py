@@ -11,7 +11,7 @@ from opty_amd import problems, hip_backend as hb
 col = opty_amd.ConstraintCollocator(**problems.build('config3_10link_small'))
 hip = col.hip
 dev = torch.device('cuda:0')
-hip.set_stream(torch.cuda.current_stream().cuda_stream)
+hip.use_torch_stream()
 free = torch.from_numpy(problems.make_free(col.num_free)).to(dev)
 con = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
 jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)

@@ -15,7 +15,7 @@ factory, fkw = problems.CONFIGS['config3_10link']
 col = opty_amd.ConstraintCollocator(emit_options=EmitOptions(groups=groups), **factory(**dict(fkw, num_nodes=20001)))
 hip = col.hip
 dev = torch.device('cuda:0')
-hip.set_stream(torch.cuda.current_stream().cuda_stream)
+hip.use_torch_stream()
 prog = col._build_program()
 M, P, ncn = prog.M, prog.P, 20000
 free = torch.from_numpy(problems.make_free(col.num_free)).to(dev)

@@ -15,7 +15,7 @@ workload = os.environ.get('OPTY_WORKLOAD', 'config3_10link')
 col = opty_amd.ConstraintCollocator(emit_options=opts, **problems.build(workload))
 hip = col.hip
 dev = torch.device('cuda:0')
-hip.set_stream(torch.cuda.current_stream().cuda_stream)
+hip.use_torch_stream()
 free = torch.from_numpy(problems.make_free(col.num_free, variable_duration=col._variable_duration)).to(dev)
 con = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
 jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)

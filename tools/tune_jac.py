@@ -51,7 +51,7 @@ def main():
             **kw)
         hip = col.hip
         build_s = time.time() - t0
-        hip.set_stream(torch.cuda.current_stream().cuda_stream)
+        hip.use_torch_stream()
         free = torch.from_numpy(problems.make_free(
             col.num_free, variable_duration=col._variable_duration)).to(dev)
         con = torch.empty(col.num_constraints, dtype=torch.float64,
