@@ -104,8 +104,9 @@ int opty_hip_destroy(opty_hip_problem *p);
 /* Use an existing hipStream_t (e.g. torch's current stream; pass
  * OPTY_HIP_STREAM_LEGACY for the default stream, whose handle is NULL) for
  * all work of this handle; NULL restores the handle's own stream.  A handle's device
- * state belongs to one stream at a time: work issued after a switch is
- * ordered behind everything the handle enqueued on the previous stream. */
+ * state belongs to one stream at a time: the first evaluation after a switch
+ * waits (on the host) for everything the handle enqueued on the previous
+ * stream. */
 int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream);
 int opty_hip_synchronize(opty_hip_problem *p);
 

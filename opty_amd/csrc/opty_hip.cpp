@@ -158,7 +158,7 @@ struct opty_hip_problem {
     double h = 0.0;
     bool have_params = false, have_known = false, have_inst = false,
          have_h = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_order = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the last enqueued work
 
     int64_t ncon_nodes() const { return d.N - 1; }
@@ -205,10 +205,20 @@ NodeRange whole(const opty_hip_problem *p) {
 // handle enqueued on the previous one: opty_uni may overwrite the table that
 // kernels of the previous stream still read, and the first fill has to be
 // visible to the new stream.
+// hipStreamSynchronize target of a handle's stream: the legacy handle is
+// synchronised through the null stream it stands for.
+hipStream_t sync_target(hipStream_t s) {
+    return s == (hipStream_t)OPTY_HIP_STREAM_LEGACY ? nullptr : s;
+}
+
 int order_streams(opty_hip_problem *p) {
     if (p->last_stream && p->last_stream != p->stream) {
-        HIP_TRY(hipEventRecord(p->ev_order, p->last_stream));
-        HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_order, 0));
+        // A switch is rare (set-up code, tests): wait for the old stream on
+        // the host.  (An event recorded on hipStreamLegacy and waited for
+        // on another stream crashed inside the runtime, ROCm 7.0.2; the
+        // legacy handle is synchronised through the null stream it stands
+        // for.)
+        HIP_TRY(hipStreamSynchronize(sync_target(p->last_stream)));
     }
     p->last_stream = p->stream;
     return 0;
@@ -353,7 +363,7 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
     if (want_jac)
         HIP_TRY(hipMemcpyAsync(jac, p->d_jac, p->nnz()*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     return 0;
 }
 
@@ -432,7 +442,7 @@ int opty_hip_objective_create(const opty_hip_objective_desc *desc,
 int opty_hip_objective_destroy(opty_hip_objective *o) {
     if (!o) return 0;
     (void)hipSetDevice(o->d.device);
-    (void)hipStreamSynchronize(o->stream);
+    (void)hipStreamSynchronize(sync_target(o->stream));
     void *bufs[] = {o->d_partial, o->d_value, o->d_free, o->d_grad};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -489,7 +499,7 @@ int opty_hip_objective_eval(opty_hip_objective *o, const double *free_,
     if (mem == OPTY_HIP_HOST && grad)
         HIP_TRY(hipMemcpyAsync(grad, o->d_grad, o->num_free()*sizeof(double),
                                hipMemcpyDeviceToHost, o->stream));
-    HIP_TRY(hipStreamSynchronize(o->stream));
+    HIP_TRY(hipStreamSynchronize(sync_target(o->stream)));
     return 0;
 }
 
@@ -585,7 +595,7 @@ int opty_hip_matrix_create(const opty_hip_matrix_desc *desc,
 int opty_hip_matrix_destroy(opty_hip_matrix *m) {
     if (!m) return 0;
     (void)hipSetDevice(m->d.device);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream) (void)hipStreamSynchronize(sync_target(m->stream));
     void *bufs[] = {m->d_args, m->d_result, m->d_const, m->d_uni};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -674,7 +684,7 @@ int opty_hip_matrix_eval(opty_hip_matrix *m, double *result,
     if (mem == OPTY_HIP_HOST) {
         HIP_TRY(hipMemcpyAsync(result, out, size*n*sizeof(double),
                                hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        HIP_TRY(hipStreamSynchronize(sync_target(m->stream)));
     }
     return 0;
 }
@@ -757,7 +767,6 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
         p->stream = p->own_stream;
         HIP_TRY(hipEventCreate(&p->ev0));
         HIP_TRY(hipEventCreate(&p->ev1));
-        HIP_TRY(hipEventCreateWithFlags(&p->ev_order, hipEventDisableTiming));
         if (desc->p_known > 0)
             HIP_TRY(hipMalloc((void **)&p->d_params,
                               desc->p_known*sizeof(double)));
@@ -780,7 +789,7 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
 int opty_hip_destroy(opty_hip_problem *p) {
     if (!p) return 0;
     (void)hipSetDevice(p->d.device);
-    (void)hipStreamSynchronize(p->stream);
+    (void)hipStreamSynchronize(sync_target(p->stream));
     void *bufs[] = {p->d_pattern, p->d_rowinfo, p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
                     p->d_cols};
@@ -788,7 +797,6 @@ int opty_hip_destroy(opty_hip_problem *p) {
         if (b) (void)hipFree(b);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
-    if (p->ev_order) (void)hipEventDestroy(p->ev_order);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
@@ -804,7 +812,7 @@ int opty_hip_set_stream(opty_hip_problem *p, void *hip_stream) {
 int opty_hip_synchronize(opty_hip_problem *p) {
     if (!p) return fail("null handle");
     if (int rc = use_device(p)) return rc;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     return 0;
 }
 
@@ -819,7 +827,7 @@ int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
     if (int rc = use_device(p)) return rc;
     HIP_TRY(hipMemcpyAsync(p->d_params, values, count*sizeof(double),
                            hipMemcpyHostToDevice, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     p->uni_dirty = true;
     p->have_params = true;
     return 0;
@@ -847,7 +855,7 @@ int opty_hip_set_known_trajectories(opty_hip_problem *p, const double *values,
                            mem == OPTY_HIP_DEVICE ? hipMemcpyDeviceToDevice
                                                   : hipMemcpyHostToDevice,
                            p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     p->have_known = true;
     return 0;
 }
@@ -1008,7 +1016,7 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
                                hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipMemcpyAsync(cols, dc, nnz*sizeof(int64_t),
                                hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipStreamSynchronize(p->stream));
+        HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
         // index arrays are setup-only: do not keep 16 bytes/entry resident
         (void)hipFree(p->d_rows);
         (void)hipFree(p->d_cols);
