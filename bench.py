@@ -451,6 +451,31 @@ def main():
                             'shared by all ranks'}
                 con_host.close()
                 jac_host.close()
+                # the same through the solver-facing service: rank 0 calls
+                # constraints(free) then jacobian(free) with NumPy arrays
+                # (H2D of `free` on every rank, evaluation, every shard to
+                # the shared host vectors, host barrier), the others serve
+                from opty_amd.sharded import ShardedCallbacks
+                cb = ShardedCallbacks(sh, name='opty_bench_cb_%d' %
+                                      os.getppid())
+                if rank == 0:
+                    hf = [f.cpu().numpy() for f in frees[:2]]
+                    cb.constraints(hf[0]), cb.jacobian(hf[0])
+                    reps = max(5, args.steps//10)
+                    t0 = time.perf_counter()
+                    for k in range(reps):
+                        cb.constraints(hf[k % 2])
+                        cb.jacobian(hf[k % 2])
+                    el = (time.perf_counter() - t0)/reps
+                    variants['callbacks'] = {
+                        'evals_per_s': 1.0/el, 'ms_per_pair': 1e3*el,
+                        'what': 'opty_amd.ShardedCallbacks: constraints(free) '
+                                '+ jacobian(free) with NumPy arrays on rank '
+                                '0, served by all ranks (the cyipopt '
+                                'callback pattern on N GPUs)'}
+                    cb.shutdown()
+                else:
+                    cb.serve()
             else:
                 variants['to_host'] = {
                     'skipped': '/dev/shm has %.0f MB free, the shared host '

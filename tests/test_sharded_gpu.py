@@ -231,7 +231,9 @@ def test_bench_strong_scaling_two_ranks():
     res = json.loads(line)
     assert res['scaling'] == 'strong' and res['n_gpus'] == 2
     assert res['config']['nodes_per_launch'] == 50000
-    assert set(res['config']['variants']) == {'gather', 'to_host'}
+    assert set(res['config']['variants']) == {'gather', 'to_host',
+                                              'callbacks'}
+    assert res['config']['variants']['callbacks']['evals_per_s'] > 0
     assert res['value'] > 0 and res['roofline']['frac'] > 0
 
 
