@@ -427,10 +427,15 @@ class ShardedCallbacks(object):
 
     _STOP, _CON, _JAC, _BOTH = 0, 1, 2, 3
 
-    def __init__(self, sharded, name=None, root=0, pin=True):
+    def __init__(self, sharded, name=None, root=0, pin=True,
+                 fresh_constraints=True):
         import torch
         import torch.distributed as dist
         sh = self.sh = sharded
+        # False: constraints(free) returns the shared buffer itself (the
+        # next call overwrites it) instead of a fresh copy (17.6 MB, 2-3 ms on
+        # one core for BASELINE config 4; cyipopt copies the result anyway)
+        self.fresh_constraints = bool(fresh_constraints)
         self.root = root
         self.is_root = sh.rank == root
         name = name or 'opty_cb_%d' % os.getppid()
@@ -483,6 +488,8 @@ class ShardedCallbacks(object):
 
     def constraints(self, free):
         self._call(free, self._CON)
+        if not self.fresh_constraints:
+            return self.con_host.array
         return np.array(self.con_host.array)        # fresh, as :2444
 
     def jacobian(self, free):
