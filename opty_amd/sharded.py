@@ -216,23 +216,31 @@ class ShardedCollocator(object):
         """Constraint nodes owned by this rank."""
         return self.b - self.a
 
-    def _global_buffers(self):
+    def _global_buffers(self, what='both'):
+        """This rank's copies of the global vectors (allocated on first use,
+        each on its own: a constraints-only destination never holds the
+        Jacobian)."""
         import torch
+        f64 = dict(dtype=torch.float64, device=self.device)
+        ncn = self.N - 1
         if self._global is None:
-            f64 = dict(dtype=torch.float64, device=self.device)
-            ncn = self.N - 1
-            self._global = (torch.empty(self.M*ncn, **f64),
-                            torch.empty(self.P*ncn, **f64))
+            self._global = [None, None]
+        if what != 'jac' and self._global[0] is None:
+            self._global[0] = torch.empty(self.M*ncn, **f64)
             self._stage = {
                 g: torch.empty((self.M, b - a), **f64)
                 for g, (a, b) in enumerate(self.ranges) if g != self.rank}
+        if what != 'con' and self._global[1] is None:
+            self._global[1] = torch.empty(self.P*ncn, **f64)
         return self._global
 
-    def _own_views(self):
-        """This rank's shard as views of the global vectors."""
-        con, jac = self._global_buffers()
-        return (con.view(self.M, self.N - 1)[:, self.a:self.b],
-                jac[self.a*self.P:self.b*self.P])
+    def _own_views(self, what='both'):
+        """This rank's shard as views of the global vectors (None for the
+        part ``what`` leaves out)."""
+        con, jac = self._global_buffers(what)
+        return (con.view(self.M, self.N - 1)[:, self.a:self.b]
+                if what != 'jac' else None,
+                jac[self.a*self.P:self.b*self.P] if what != 'con' else None)
 
     # -- evaluation (no collective) ----------------------------------------------
     def _hip_evaluate(self, free, con2d, jac1d, a, b, what='both'):
@@ -288,33 +296,43 @@ class ShardedCollocator(object):
         return free
 
     # -- re-assembly (the only communication) ---------------------------------------
-    def _exchange(self, dsts):
-        """Every rank sends its two shards to every rank in ``dsts`` (but
-        itself); destinations receive the Jacobian slices in place and the
-        constraint blocks into staging.  One batch of point-to-point ops:
-        shard sizes differ by up to one node, which an all-gather of equal
-        pieces cannot express without padding copies."""
+    def _exchange(self, dsts, what='both'):
+        """Every rank sends its shards (``what``: both, ``'con'`` or ``'jac'``)
+        to every rank in ``dsts`` (but itself); destinations receive the
+        Jacobian slices in place and the constraint blocks into staging.  One
+        batch of point-to-point ops: shard sizes differ by up to one node,
+        which an all-gather of equal pieces cannot express without padding
+        copies."""
         import torch.distributed as dist
+        want_con, want_jac = what != 'jac', what != 'con'
         recvs, sends = [], []               # (device tensor, peer)
         if self.rank in dsts:
-            con_g, jac_g = self._global_buffers()
+            con_g, jac_g = self._global_buffers(what)
             if not self._in_place:
-                own_con, own_jac = self._own_views()
-                own_con.copy_(self.con_local)
-                own_jac.copy_(self.jac_local)
+                own_con, own_jac = self._own_views(what)
+                if want_con:
+                    own_con.copy_(self.con_local)
+                if want_jac:
+                    own_jac.copy_(self.jac_local)
             for g, (a, b) in enumerate(self.ranges):
                 if g != self.rank:
-                    recvs.append((jac_g[a*self.P:b*self.P], g))
-                    recvs.append((self._stage[g], g))
-        src_con, src_jac = (self._own_views() if self._in_place
+                    if want_jac:
+                        recvs.append((jac_g[a*self.P:b*self.P], g))
+                    if want_con:
+                        recvs.append((self._stage[g], g))
+        src_con, src_jac = (self._own_views(what) if self._in_place
                             else (self.con_local, self.jac_local))
-        if self._in_place and any(d != self.rank for d in dsts):
+        if self._in_place and want_con and \
+                any(d != self.rank for d in dsts):
             # the constraint shard inside the global vector is strided
             self.con_local.copy_(src_con)
             src_con = self.con_local
         for d in dsts:
             if d != self.rank:
-                sends += [(src_jac, d), (src_con, d)]
+                if want_jac:
+                    sends.append((src_jac, d))
+                if want_con:
+                    sends.append((src_con, d))
         # gloo moves host memory only: a GPU run that rendezvoused with gloo
         # (several ranks sharing one GPU on a development box -- RCCL refuses
         # duplicate devices) stages the messages through the host
@@ -332,19 +350,21 @@ class ShardedCollocator(object):
             for buf, (t, _) in zip(landing, recvs):
                 t.copy_(buf)
         if self.rank in dsts:
-            con2d = con_g.view(self.M, self.N - 1)
-            for g, (a, b) in enumerate(self.ranges):
-                if g != self.rank:
-                    con2d[:, a:b].copy_(self._stage[g])
+            if want_con:
+                con2d = con_g.view(self.M, self.N - 1)
+                for g, (a, b) in enumerate(self.ranges):
+                    if g != self.rank:
+                        con2d[:, a:b].copy_(self._stage[g])
             return con_g, jac_g
         return None
 
-    def gather(self, dst=0):
+    def gather(self, dst=0, what='both'):
         """Gather-v of the last :meth:`evaluate` to rank ``dst``: returns the
         full equation-major constraint vector and node-major Jacobian value
         vector there (device tensors owned by this object, overwritten by the
-        next call), ``None`` on the other ranks."""
-        return self._exchange([dst])
+        next call; the one ``what`` leaves out is None), ``None`` on the
+        other ranks."""
+        return self._exchange([dst], what)
 
     def all_gather(self):
         """The full vectors on every rank."""
@@ -432,9 +452,9 @@ class ShardedCallbacks(object):
         import torch
         import torch.distributed as dist
         sh = self.sh = sharded
-        # False: constraints(free) returns the shared buffer itself (the
-        # next call overwrites it) instead of a fresh copy (17.6 MB, 2-3 ms on
-        # one core for BASELINE config 4; cyipopt copies the result anyway)
+        # False: constraints(free) may return a buffer the next call
+        # overwrites instead of a fresh array (cyipopt copies the result
+        # anyway)
         self.fresh_constraints = bool(fresh_constraints)
         self.root = root
         self.is_root = sh.rank == root
@@ -443,30 +463,55 @@ class ShardedCallbacks(object):
         nfree = sh._num_free()
         gpu = sh.device.type == 'cuda'
         pin = bool(pin and gpu)
-        self.free_host = SharedHostVector(name + '_free', nfree, sh.rank,
-                                          sh.group, root, pin)
-        self.con_host = SharedHostVector(name + '_con', sh.M*ncn, sh.rank,
-                                         sh.group, root, pin)
+        # Over RCCL the small vectors travel GPU to GPU: `free` (18 MB for
+        # config 4) goes up once on the root and is broadcast over xGMI, the
+        # constraint shards (2 MB each) are gathered to the root's GPU and
+        # come down as one fresh array -- a single-threaded host memcpy of
+        # either costs more than that.  Only the Jacobian, the 792 MB that
+        # matter, goes through the shared page-locked host vector, every
+        # shard over its own PCIe link.  Under gloo (CPU tests, several ranks
+        # on one GPU) everything goes through shared host vectors.
+        self._rccl = gpu and dist.get_backend(sh.group) == 'nccl'
+        self.free_host = self.con_host = None
+        if not self._rccl:
+            self.free_host = SharedHostVector(name + '_free', nfree, sh.rank,
+                                              sh.group, root, pin)
+            self.con_host = SharedHostVector(name + '_con', sh.M*ncn,
+                                             sh.rank, sh.group, root, pin)
         self.jac_host = SharedHostVector(
             name + '_jac', sh.P*ncn, sh.rank, sh.group, root,
             (sh.a*sh.P, sh.b*sh.P) if pin else False)
+        self.num_free = nfree
         self.free_dev = torch.empty(nfree, dtype=torch.float64,
                                     device=sh.device)
-        # the command travels by broadcast; gloo moves host memory
-        on_dev = gpu and dist.get_backend(sh.group) != 'gloo'
         self._cmd = torch.zeros(1, dtype=torch.int64,
-                                device=sh.device if on_dev else 'cpu')
+                                device=sh.device if self._rccl else 'cpu')
+        self._pending = self._con_dev = None
         self._dist = dist
 
     # -- one evaluation, on every rank ------------------------------------------
     def _round(self, cmd):
+        import torch
         what = {self._CON: 'con', self._JAC: 'jac', self._BOTH: 'both'}[cmd]
-        self.free_dev.copy_(self.free_host.torch_view(), non_blocking=True)
+        if self._rccl:
+            if self.is_root:
+                self.free_dev.copy_(torch.from_numpy(self._pending))
+            self._dist.broadcast(self.free_dev, self.root,
+                                 group=self.sh.group)
+        else:
+            self.free_dev.copy_(self.free_host.torch_view(),
+                                non_blocking=True)
         self.sh.evaluate(self.free_dev, what=what)
-        self.sh.to_host(self.con_host if what != 'jac' else None,
-                        self.jac_host if what != 'con' else None)
+        if what != 'jac':
+            if self._rccl:
+                got = self.sh.gather(self.root, what='con')
+                if self.is_root:
+                    self._con_dev = got[0]
+            else:
+                self.sh.to_host(self.con_host, None)
+        if what != 'con':
+            self.sh.to_host(None, self.jac_host)
         if self.sh.device.type == 'cuda':
-            import torch
             torch.cuda.synchronize(self.sh.device)
         self._dist.barrier(self.sh.group)      # every shard has landed
 
@@ -478,19 +523,28 @@ class ShardedCallbacks(object):
     # -- the solver's side (rank `root`) -------------------------------------------
     def _call(self, free, cmd):
         assert self.is_root, 'callbacks run on the root rank; others serve()'
-        free = np.asarray(free, dtype=np.float64)
-        if free.shape != (self.free_host.count,):
+        free = np.ascontiguousarray(free, dtype=np.float64)
+        if free.shape != (self.num_free,):
             raise ValueError('free must have shape ({},), got {}'.format(
-                self.free_host.count, free.shape))
-        self.free_host.array[:] = free
+                self.num_free, free.shape))
+        if self._rccl:
+            self._pending = free
+        else:
+            self.free_host.array[:] = free
         self._command(cmd)
         self._round(cmd)
+        self._pending = None
+
+    def _constraints_result(self):
+        if self._rccl:
+            return self._con_dev.cpu().numpy()       # fresh, as :2444
+        if not self.fresh_constraints:
+            return self.con_host.array
+        return np.array(self.con_host.array)         # fresh, as :2444
 
     def constraints(self, free):
         self._call(free, self._CON)
-        if not self.fresh_constraints:
-            return self.con_host.array
-        return np.array(self.con_host.array)        # fresh, as :2444
+        return self._constraints_result()
 
     def jacobian(self, free):
         self._call(free, self._JAC)
@@ -498,7 +552,7 @@ class ShardedCallbacks(object):
 
     def constraints_and_jacobian(self, free):
         self._call(free, self._BOTH)
-        return np.array(self.con_host.array), self.jac_host.array
+        return self._constraints_result(), self.jac_host.array
 
     def shutdown(self):
         """Releases the serving ranks (root only; idempotent)."""
@@ -520,4 +574,5 @@ class ShardedCallbacks(object):
     def close(self):
         self._cmd = None
         for v in (self.free_host, self.con_host, self.jac_host):
-            v.close()
+            if v is not None:
+                v.close()
