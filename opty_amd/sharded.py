@@ -434,13 +434,15 @@ class ShardedCallbacks(object):
     served by all ranks of a node-sharded problem.
 
     The solver (IPOPT) runs in ONE process, rank ``root``; the other ranks
-    call :meth:`serve` and wait.  A callback on the root writes ``free`` into a
-    page-locked host vector shared by all processes and broadcasts a command;
-    every rank then loads ``free`` over its own PCIe link, evaluates its node
-    range and copies its shard straight into the shared, page-locked output
-    vectors -- the host-visible rate scales with the number of PCIe links
-    instead of funnelling the 792 MB Jacobian of BASELINE config 4 through one
-    (``to_host``).  Layouts are the reference's
+    call :meth:`serve` and wait.  A callback on the root broadcasts a command
+    and ``free``; every rank evaluates its node range and copies its Jacobian
+    shard straight into a page-locked host vector shared by all processes --
+    the host-visible rate scales with the number of PCIe links instead of
+    funnelling the 792 MB Jacobian of BASELINE config 4 through one
+    (``to_host``).  The small vectors take the cheapest
+    way: over RCCL ``free`` is uploaded once and broadcast GPU to GPU, the
+    constraint shards are gathered to the root's GPU; under gloo both go
+    through shared host vectors as well.  Layouts are the reference's
     (``opty/direct_collocation.py:2446``, ``:2885-2887``): ``constraints``
     returns a fresh array, ``jacobian`` the persistent shared buffer.
     """

@@ -318,3 +318,53 @@ def test_sharded_problem_callbacks_from_two_ranks(tmp_path):
     gu.assert_close(z['c2'], con(z['f1']), 1e-12,
                     what='sharded problem con 2', bound=cb)
     assert np.isfinite(z['obj'][0])
+
+
+def _rccl_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    from opty_amd.sharded import ShardedCollocator, ShardedCallbacks
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', 0))
+    try:
+        torch.cuda.set_device(0)
+        factory, fkw = problems.CONFIGS['config3_10link']
+        kw = factory(**dict(fkw, num_nodes=5001))
+        sh = ShardedCollocator(device='cuda:0', **kw)
+        cb = ShardedCallbacks(sh, name='opty_t_rccl_%d' % port)
+        assert cb._rccl and cb.free_host is None
+        frees = [problems.make_free(sh.collocator.num_free, seed=s)
+                 for s in (1, 2)]
+        c1 = cb.constraints(frees[0])
+        j1 = cb.jacobian(frees[0]).copy()
+        c2, j2 = cb.constraints_and_jacobian(frees[1])
+        np.savez(out, f1=frees[0], f2=frees[1], c1=c1, j1=j1, c2=c2,
+                 j2=j2.copy())
+        cb.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_callbacks_over_rccl_single_rank(tmp_path):
+    """The RCCL branch of ``ShardedCallbacks`` (``free`` broadcast GPU to GPU,
+    constraints gathered on the root's GPU, Jacobian through the shared
+    page-locked vector) -- with the one rank a 1-GPU box can give RCCL."""
+    import torch.multiprocessing as mp
+    import opty_amd
+    out = str(tmp_path/'rccl.npz')
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    z = np.load(out)
+    factory, fkw = problems.CONFIGS['config3_10link']
+    col = opty_amd.ConstraintCollocator(**factory(**dict(fkw,
+                                                         num_nodes=5001)))
+    con, jac = (col.generate_constraint_function(),
+                col.generate_jacobian_function())
+    # the separate kernels of the same code object: bit for bit
+    np.testing.assert_array_equal(z['c1'], con(z['f1']))
+    np.testing.assert_array_equal(z['j1'], jac(z['f1']))
+    # constraints_and_jacobian runs the fused kernel: same expressions,
+    # scheduled (FMA-contracted) on their own
+    np.testing.assert_allclose(z['c2'], con(z['f2']), rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(z['j2'], jac(z['f2']), rtol=1e-11, atol=1e-9)
