@@ -449,15 +449,13 @@ def main():
                     'what': 'eval + every rank copies its shard over its '
                             'own PCIe link into one page-locked host vector '
                             'shared by all ranks'}
-                con_host.close()
-                jac_host.close()
                 # the same through the solver-facing service: rank 0 calls
                 # constraints(free) then jacobian(free) with NumPy arrays
                 # (H2D of `free` on every rank, evaluation, every shard to
                 # the shared host vectors, host barrier), the others serve
                 from opty_amd.sharded import ShardedCallbacks
                 cb = ShardedCallbacks(sh, name='opty_bench_cb_%d' %
-                                      os.getppid())
+                                      os.getppid(), jac_host=jac_host)
                 if rank == 0:
                     hf = [f.cpu().numpy() for f in frees[:2]]
                     cb.constraints(hf[0]), cb.jacobian(hf[0])
@@ -476,6 +474,8 @@ def main():
                     cb.shutdown()
                 else:
                     cb.serve()
+                con_host.close()
+                jac_host.close()
             else:
                 variants['to_host'] = {
                     'skipped': '/dev/shm has %.0f MB free, the shared host '

@@ -84,18 +84,39 @@ class SharedHostVector(object):
         self.count = int(count)
         self._pinned = False
         multi = dist.is_available() and dist.is_initialized()
+        error = None
         if rank == owner:
             # reserve the pages now: a full /dev/shm raises here (ENOSPC)
             # instead of a SIGBUS at the first write
-            fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
             try:
-                os.posix_fallocate(fd, 0, max(8, 8*self.count))
-            finally:
-                os.close(fd)
-            self.array = np.memmap(self.path, dtype=np.float64, mode='r+',
-                                   shape=(self.count,))
+                fd = os.open(self.path, os.O_CREAT | os.O_RDWR | os.O_TRUNC,
+                             0o600)
+                try:
+                    os.posix_fallocate(fd, 0, max(8, 8*self.count))
+                finally:
+                    os.close(fd)
+                self.array = np.memmap(self.path, dtype=np.float64,
+                                       mode='r+', shape=(self.count,))
+            except OSError as err:
+                error = err
+                try:
+                    os.unlink(self.path)
+                except OSError:
+                    pass
         if multi:
-            dist.barrier(group)
+            # every rank learns whether the owner succeeded: a failure must
+            # not leave the others waiting at a barrier
+            import torch
+            on_gpu = dist.get_backend(group) == 'nccl'
+            ok = torch.tensor([0 if error else 1], dtype=torch.int32,
+                              device='cuda' if on_gpu else 'cpu')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if ok.item() == 0:
+                raise OSError('could not create the shared host vector %s '
+                              '(%d bytes): %s' % (self.path, 8*self.count,
+                                                  error or 'owner failed'))
+        elif error:
+            raise error
         if rank != owner:
             self.array = np.memmap(self.path, dtype=np.float64, mode='r+',
                                    shape=(self.count,))
@@ -120,10 +141,13 @@ class SharedHostVector(object):
                                            else hi])
 
     def close(self):
+        """Unpins the vector; the mapping itself lives as long as any array
+        handed out refers to it."""
         if self._pinned:
             from . import hip_backend as hb
             hb.host_unregister(self._pin_view)
             self._pinned = False
+        self._pin_view = None
 
     def __del__(self):
         try:
@@ -450,7 +474,7 @@ class ShardedCallbacks(object):
     _STOP, _CON, _JAC, _BOTH = 0, 1, 2, 3
 
     def __init__(self, sharded, name=None, root=0, pin=True,
-                 fresh_constraints=True):
+                 fresh_constraints=True, jac_host=None):
         import torch
         import torch.distributed as dist
         sh = self.sh = sharded
@@ -480,9 +504,12 @@ class ShardedCallbacks(object):
                                               sh.group, root, pin)
             self.con_host = SharedHostVector(name + '_con', sh.M*ncn,
                                              sh.rank, sh.group, root, pin)
-        self.jac_host = SharedHostVector(
-            name + '_jac', sh.P*ncn, sh.rank, sh.group, root,
-            (sh.a*sh.P, sh.b*sh.P) if pin else False)
+        # ``jac_host``: an existing shared vector of P*(N-1) doubles to use
+        # (the caller keeps ownership)
+        self._own_jac_host = jac_host is None
+        self.jac_host = jac_host if jac_host is not None else \
+            SharedHostVector(name + '_jac', sh.P*ncn, sh.rank, sh.group, root,
+                             (sh.a*sh.P, sh.b*sh.P) if pin else False)
         self.num_free = nfree
         self.free_dev = torch.empty(nfree, dtype=torch.float64,
                                     device=sh.device)
@@ -575,6 +602,7 @@ class ShardedCallbacks(object):
 
     def close(self):
         self._cmd = None
-        for v in (self.free_host, self.con_host, self.jac_host):
+        for v in (self.free_host, self.con_host,
+                  self.jac_host if self._own_jac_host else None):
             if v is not None:
                 v.close()
