@@ -411,77 +411,80 @@ def main():
             extras['serial_evals_per_s'] = args.steps*(
                 1 if strong else world)/el
         if world > 1 and strong:
-            # re-assembly variants of SURVEY.md 8(e); rank 0 is where IPOPT
-            # would run and evaluates its own shard in place
-            variants = {}
-            ncn = N - 1
+            try:
+                # re-assembly variants of SURVEY.md 8(e); rank 0 is where IPOPT
+                # would run and evaluates its own shard in place
+                variants = {}
+                ncn = N - 1
 
-            def gather_step(k):
-                sh.evaluate(frees[k % 4], in_place=(rank == 0))
-                sh.gather(0)
-            el = timed(gather_step, args.steps, args.warmup)
-            variants['gather'] = {
-                'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
-                'what': 'eval + point-to-point gather-v of con and jac to '
-                        'rank 0 (%s)' % dist.get_backend()}
-            # a /dev/shm too small for the 810 MB is the one failure that
-            # must not take the headline line down: probe it on rank 0 first
-            # and let every rank know
-            st = os.statvfs('/dev/shm')
-            room = torch.tensor([float(st.f_bavail*st.f_frsize)],
-                                dtype=torch.float64,
-                                device=dev if not oversub else 'cpu')
-            dist.broadcast(room, 0)
-            if room.item() > 8.0*(M + P)*ncn*1.05:
-                con_host = SharedHostVector(
-                    'opty_bench_con_%d' % os.getppid(), M*ncn, rank)
-                jac_host = SharedHostVector(
-                    'opty_bench_jac_%d' % os.getppid(), P*ncn, rank,
-                    pin=(a*P, b*P))     # the slice this rank writes
+                def gather_step(k):
+                    sh.evaluate(frees[k % 4], in_place=(rank == 0))
+                    sh.gather(0)
+                el = timed(gather_step, args.steps, args.warmup)
+                variants['gather'] = {
+                    'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
+                    'what': 'eval + point-to-point gather-v of con and jac to '
+                            'rank 0 (%s)' % dist.get_backend()}
+                # a /dev/shm too small for the 810 MB is the one failure that
+                # must not take the headline line down: probe it on rank 0 first
+                # and let every rank know
+                st = os.statvfs('/dev/shm')
+                room = torch.tensor([float(st.f_bavail*st.f_frsize)],
+                                    dtype=torch.float64,
+                                    device=dev if not oversub else 'cpu')
+                dist.broadcast(room, 0)
+                if room.item() > 8.0*(M + P)*ncn*1.05:
+                    con_host = SharedHostVector(
+                        'opty_bench_con_%d' % os.getppid(), M*ncn, rank)
+                    jac_host = SharedHostVector(
+                        'opty_bench_jac_%d' % os.getppid(), P*ncn, rank,
+                        pin=(a*P, b*P))     # the slice this rank writes
 
-                def host_step(k):
-                    sh.evaluate(frees[k % 4])
-                    sh.to_host(con_host, jac_host)
-                el = timed(host_step, args.steps, args.warmup)
-                variants['to_host'] = {
-                    'evals_per_s': args.steps/el,
-                    'ms_per_step': 1e3*el/args.steps,
-                    'what': 'eval + every rank copies its shard over its '
-                            'own PCIe link into one page-locked host vector '
-                            'shared by all ranks'}
-                # the same through the solver-facing service: rank 0 calls
-                # constraints(free) then jacobian(free) with NumPy arrays
-                # (H2D of `free` on every rank, evaluation, every shard to
-                # the shared host vectors, host barrier), the others serve
-                from opty_amd.sharded import ShardedCallbacks
-                cb = ShardedCallbacks(sh, name='opty_bench_cb_%d' %
-                                      os.getppid(), jac_host=jac_host)
-                if rank == 0:
-                    hf = [f.cpu().numpy() for f in frees[:2]]
-                    cb.constraints(hf[0]), cb.jacobian(hf[0])
-                    reps = max(5, args.steps//10)
-                    t0 = time.perf_counter()
-                    for k in range(reps):
-                        cb.constraints(hf[k % 2])
-                        cb.jacobian(hf[k % 2])
-                    el = (time.perf_counter() - t0)/reps
-                    variants['callbacks'] = {
-                        'evals_per_s': 1.0/el, 'ms_per_pair': 1e3*el,
-                        'what': 'opty_amd.ShardedCallbacks: constraints(free) '
-                                '+ jacobian(free) with NumPy arrays on rank '
-                                '0, served by all ranks (the cyipopt '
-                                'callback pattern on N GPUs)'}
-                    cb.shutdown()
+                    def host_step(k):
+                        sh.evaluate(frees[k % 4])
+                        sh.to_host(con_host, jac_host)
+                    el = timed(host_step, args.steps, args.warmup)
+                    variants['to_host'] = {
+                        'evals_per_s': args.steps/el,
+                        'ms_per_step': 1e3*el/args.steps,
+                        'what': 'eval + every rank copies its shard over its '
+                                'own PCIe link into one page-locked host vector '
+                                'shared by all ranks'}
+                    # the same through the solver-facing service: rank 0 calls
+                    # constraints(free) then jacobian(free) with NumPy arrays
+                    # (H2D of `free` on every rank, evaluation, every shard to
+                    # the shared host vectors, host barrier), the others serve
+                    from opty_amd.sharded import ShardedCallbacks
+                    cb = ShardedCallbacks(sh, name='opty_bench_cb_%d' %
+                                          os.getppid(), jac_host=jac_host)
+                    if rank == 0:
+                        hf = [f.cpu().numpy() for f in frees[:2]]
+                        cb.constraints(hf[0]), cb.jacobian(hf[0])
+                        reps = max(5, args.steps//10)
+                        t0 = time.perf_counter()
+                        for k in range(reps):
+                            cb.constraints(hf[k % 2])
+                            cb.jacobian(hf[k % 2])
+                        el = (time.perf_counter() - t0)/reps
+                        variants['callbacks'] = {
+                            'evals_per_s': 1.0/el, 'ms_per_pair': 1e3*el,
+                            'what': 'opty_amd.ShardedCallbacks: constraints(free) '
+                                    '+ jacobian(free) with NumPy arrays on rank '
+                                    '0, served by all ranks (the cyipopt '
+                                    'callback pattern on N GPUs)'}
+                        cb.shutdown()
+                    else:
+                        cb.serve()
+                    con_host.close()
+                    jac_host.close()
                 else:
-                    cb.serve()
-                con_host.close()
-                jac_host.close()
-            else:
-                variants['to_host'] = {
-                    'skipped': '/dev/shm has %.0f MB free, the shared host '
-                               'vectors need %.0f MB' % (
-                                   room.item()/1e6, 8.0*(M + P)*ncn/1e6)}
-            extras['variants'] = variants
+                    variants['to_host'] = {
+                        'skipped': '/dev/shm has %.0f MB free, the shared host '
+                                   'vectors need %.0f MB' % (
+                                       room.item()/1e6, 8.0*(M + P)*ncn/1e6)}
+                extras['variants'] = variants
+            except Exception as err:      # the headline line must survive
+                extras['variants_error'] = repr(err)
         if world == 1:
             extras['other_configs'] = other_configs(dev, max(20,
                                                              args.steps//4))
