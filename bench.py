@@ -181,14 +181,15 @@ def cpu_baseline(kw, budget_s=24.0):
                    cpu['logical_cpus'], cpu['numa_nodes'], detail))
 
 
-def lookup_traffic(sha, kernel):
+def lookup_traffic(kernel_sha):
     """HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     collected separately with rocprofv3 as the microarch guide prescribes;
-    summaries under profiles/), keyed on the sha-256 of the generated module
-    the counters were collected on: a changed kernel yields ``None``."""
+    summaries under profiles/), keyed on the sha-256 of the generated source
+    of the kernel the counters were collected on (N = 100 000 launch): a
+    changed kernel yields ``None``."""
     try:
         with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
-            return json.load(f)[sha][kernel]['hbm_bytes_per_launch']
+            return json.load(f)[kernel_sha]['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError, TypeError):
         return None
 
@@ -504,7 +505,9 @@ def main():
             dom, dom_ms = 'opty_conjac', fused_ms
             dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
         achieved = dom_bytes/(dom_ms*1e-3)/1e9
-        traffic = lookup_traffic(col._kernel_meta['sha'], dom) \
+        kmeta = col._kernel_meta['kernels'][
+            'jac' if args.serial else 'conjac']
+        traffic = lookup_traffic(kmeta['sha']) \
             if (world == 1 and args.nodes == 100000) else None
         value = args.steps*(1 if strong else world)/elapsed
         nnz_total = P*(N - 1)*(1 if strong else world)
@@ -538,6 +541,7 @@ def main():
                 'oversubscribed': bool(oversub),
                 'prewarm_ms': args.prewarm_ms,
                 'code_object_sha': col._kernel_meta['sha'][:16],
+                'kernel_sha': kmeta['sha'][:16],
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
                 'GBps_nnz_written': 8.0*P*cnt/(jac_ms*1e-3)/1e9,

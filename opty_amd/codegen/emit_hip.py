@@ -60,6 +60,10 @@ STRIP_ENTRIES = 100
 #: for P = 666 / 990 / 1830 / 5100, i.e. about 0.286 sqrt(P) (an empirical fit
 #: over that family; off by one strip costs 1-3 %, the r01 choice cost 7 %).
 FUSED_STRIPS_PER_SQRT_ENTRY = 0.286
+#: constraint vector of one launch above which the fused kernel streams its
+#: constraint stores past the caches (between the 70 MB of N = 4*10^5, still
+#: fine with plain stores, and the 176 MB of N = 10^6)
+CON_CACHE_BYTES = 128 << 20
 
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
@@ -81,7 +85,11 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0, pad=0, occupancy=0):
+                 interleave=0, pad=0, occupancy=0, con_nt=None):
+        # non-temporal constraint stores: None = automatic (opty_con always;
+        # opty_conjac when the constraint vector of a launch is too large to
+        # stay in the caches, see emit_module), 0 / 1 = never / always
+        self.con_nt = None if con_nt is None else int(con_nt)
         # experiment: ask the compiler for that many waves per SIMD
         # (amdgpu_waves_per_eu: 2 caps the kernels at 256 VGPRs)
         self.occupancy = int(occupancy)
@@ -126,7 +134,9 @@ class EmitOptions(object):
                     self.flush_unroll, self.waves, self.store_aux,
                     self.con_rows_per_wave, self.interleave) +
                 (' pad=%d' % self.pad if self.pad else '') +
-                (' occupancy=%d' % self.occupancy if self.occupancy else ''))
+                (' occupancy=%d' % self.occupancy if self.occupancy else '') +
+                (' con_nt=%d' % self.con_nt if self.con_nt is not None
+                 else ''))
 
 
 def _lit(v):
@@ -353,6 +363,7 @@ class _ModuleWriter(object):
         self.dag = prog.dag
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
         self._auto = None           # (G_live, G) of group_ranges()
+        self._con_nt = False        # constraint stores of the kernel in print
 
     # -- leaves -------------------------------------------------------------
     def _is_vec_input(self, i):
@@ -601,8 +612,14 @@ class _ModuleWriter(object):
         for j in con_rows:
             body.new_scope()      # fetches hoisted per row, not per kernel
             ref = body.emit(p.con_out[j])
-            body.lines.append('if (valid) con[%dLL*con_stride + node] = %s;'
-                              % (j, ref))
+            if self._con_nt:
+                body.lines.append(
+                    'if (valid) __builtin_nontemporal_store(%s, '
+                    '&con[%dLL*con_stride + node]);' % (ref, j))
+            else:
+                body.lines.append(
+                    'if (valid) con[%dLL*con_stride + node] = %s;'
+                    % (j, ref))
         nv = '(N < 0 ? nvalid : 0)' if self.o.ablate == 'compute_only' \
             else 'nvalid'
 
@@ -782,12 +799,13 @@ class _ModuleWriter(object):
     (void)ncn;
 '''
 
-    def kernel(self, name, groups, con_of_group, W=1):
+    def kernel(self, name, groups, con_of_group, W=1, con_nt=False):
         """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
         wave; ``con_of_group[g]`` = constraint rows stored by wave g.  A
         workgroup is ``W`` consecutive groups of one 64-node block: they share
         one input slab (filled cooperatively) and each owns a ring tile."""
         G = len(groups)
+        self._con_nt = bool(con_nt)
         keep = [True]*G
         if self.o.ablate in ('only_cheap', 'only_dear'):
             cheap = [sum(self._strip_cost(*rg) for rg in grp if rg[1] > rg[0])
@@ -826,9 +844,13 @@ class _ModuleWriter(object):
             src.append('    default: break;')
             src.append('    }')
         src.append('}')
-        return '\n'.join(src), dict(name=name, groups=G, waves_per_wg=W,
-                                    wgs_per_block=sets,
-                                    lds_bytes=lds_doubles*8)
+        text = '\n'.join(src)
+        # sha of this kernel's own source: profiles/traffic.json keys the PMC
+        # counters on it, so that they go stale with the kernel they were
+        # collected on and not with a change elsewhere in the module
+        return text, dict(name=name, groups=G, waves_per_wg=W,
+                          wgs_per_block=sets, lds_bytes=lds_doubles*8,
+                          sha=hashlib.sha256(text.encode()).hexdigest())
 
     @staticmethod
     def _waves_per_workgroup(slab_rows, ring_rows, lds_per_cu=160*1024):
@@ -1072,12 +1094,24 @@ def emit_module(prog, opts=None, node_blocks=None):
     con_of = [[] for _ in fused_jac] + con_sets
     parts = []
     kernels = {}
-    for key, name, grp, cons, wpw in (
-            ('con', 'opty_con', con_groups, con_sets, 1),
+    # Constraint stores.  Written once, never re-read by the kernels: on their
+    # own (opty_con) they are fastest streamed past the caches (10-link,
+    # N = 10^5: 0.0118 vs 0.0137 ms).  In the fused kernel a constraint vector
+    # that fits the caches is better left to them (N = 10^5, 17.6 MB: 0.1359
+    # vs 0.1465 ms), one that does not evicts into the Jacobian stream
+    # (N = 10^6, 176 MB: 1.598 ms plain, 1.366 ms non-temporal) --
+    # profiles/r02_strip_sweeps.txt.
+    con_bytes = 8*prog.M*64*int(node_blocks or 0)
+    nt_alone = opts.con_nt != 0
+    nt_fused = opts.con_nt == 1 or (opts.con_nt is None and
+                                    con_bytes > CON_CACHE_BYTES)
+    for key, name, grp, cons, wpw, nt in (
+            ('con', 'opty_con', con_groups, con_sets, 1, nt_alone),
             ('jac', 'opty_jac', list(groups) + [[(0, 0)]]*opts.pad,
-             [[] for _ in range(len(groups) + opts.pad)], opts.waves),
-            ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves)):
-        src, meta = w.kernel(name, grp, cons, wpw)
+             [[] for _ in range(len(groups) + opts.pad)], opts.waves, False),
+            ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves,
+             nt_fused)):
+        src, meta = w.kernel(name, grp, cons, wpw, nt)
         parts += [src, '']
         kernels[key] = meta
     if prog.inst_con_out:
