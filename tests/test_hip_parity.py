@@ -671,3 +671,49 @@ def test_million_node_problem_device_windows():
     # the nodes in between are finite and not left unwritten
     probe = jv[::9973]
     assert torch.isfinite(probe).all()
+
+
+@pytest.mark.parametrize('overrides,N,explicit', [
+    (dict(num_links=10), 66, False), (dict(num_links=10), 1025, False),
+    (dict(num_links=10, variable_duration=True, unknown_masses=2), 130,
+     False),
+    (dict(num_links=3, method='midpoint', unknown_masses=1), 3, True),
+    (dict(num_links=3, method='midpoint', unknown_masses=1), 131, True)])
+def test_small_launch_geometry_matches_default(overrides, N, explicit):
+    """The two-waves-per-SIMD geometry the printer picks for small launches
+    (16-entry chunks, 4-wave workgroups sharing one slab, 256-VGPR cap;
+    ``emit_hip._dual_occupancy_cut``) evaluates the same DAG as the default
+    geometry: ragged node counts, unknown parameters and variable duration
+    (the automatic choice for a 12 500-node launch), and midpoint (the same
+    options set by hand: the rule itself only fires for 10-link-sized
+    blocks)."""
+    import opty_amd
+    from opty_amd.codegen.emit_hip import EmitOptions
+    kw = problems.n_link_cart_pendulum(num_nodes=N, **overrides)
+    default = opty_amd.ConstraintCollocator(**kw)
+    if explicit:
+        small = opty_amd.ConstraintCollocator(
+            emit_options=EmitOptions(chunk=16, waves=4, occupancy=2,
+                                     groups=3), **kw)
+    else:
+        small = opty_amd.ConstraintCollocator(launch_nodes=12500, **kw)
+    meta = small.generate_source()[1]
+    assert meta['kernels']['conjac']['waves_per_wg'] == 4
+    assert 'amdgpu_waves_per_eu(2, 2)' in small.generate_source()[0]
+    assert default.generate_source()[1]['kernels']['conjac'][
+        'waves_per_wg'] == 1
+    free = problems.make_free(default.num_free, seed=13,
+                              variable_duration=default._variable_duration)
+    cb, jb = gu.error_bounds(default, free)
+    c0 = default.generate_constraint_function()(free)
+    j0 = default.generate_jacobian_function()(free).copy()
+    gu.assert_close(small.generate_constraint_function()(free), c0, 1e-12,
+                    what='small-launch con', bound=cb)
+    gu.assert_close(small.generate_jacobian_function()(free), j0, 1e-12,
+                    what='small-launch jac', bound=jb)
+    # the fused kernel of that geometry as well
+    from opty_amd import hip_backend as hb
+    c2, j2 = np.empty_like(c0), np.empty_like(j0)
+    small.hip.eval_con_jac(free, c2, j2, hb.HOST)
+    gu.assert_close(c2, c0, 1e-12, what='small-launch fused con', bound=cb)
+    gu.assert_close(j2, j0, 1e-12, what='small-launch fused jac', bound=jb)
