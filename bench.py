@@ -101,7 +101,7 @@ def cpu_baseline(kw, budget_s=24.0):
     2444-2446``); the persistent-buffer variant is reported beside it."""
     import numpy as np
     from oracle.collocation_oracle import OracleCollocator, split_free
-    from opty_amd import problems
+    from examples import problems
     cpu = host_cpu()
     cores = cpu['physical_cores']
     orc = OracleCollocator(name='config3_10link', parallel=True, **kw)
@@ -199,7 +199,8 @@ def other_configs(dev, iters):
     config-5 stand-in on this GPU (hipEvent-timed, single GPU)."""
     import torch
     import opty_amd
-    from opty_amd import problems, hip_backend as hb
+    from opty_amd import hip_backend as hb
+    from examples import problems
     out = {}
     for name in ('config2_pendulum', 'config5_standin_24link'):
         col = opty_amd.ConstraintCollocator(device=dev.index,
@@ -252,7 +253,7 @@ def host_path(kw, dev_index, reps=7):
     NumPy out through ``generate_*_function`` (PCIe inclusive), for the
     reference's dense-block pattern and for ``prune_zeros=True``."""
     import opty_amd
-    from opty_amd import problems
+    from examples import problems
 
     def med(fn, frees):
         fn(frees[0])
@@ -304,7 +305,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from opty_amd import problems, hip_backend as hb
+    from opty_amd import hip_backend as hb
+    from examples import problems
     from opty_amd.sharded import ShardedCollocator, SharedHostVector
 
     rank = int(os.environ.get('RANK', 0))

@@ -1,4 +1,5 @@
-"""Problem zoo: the direct-collocation problems BASELINE.json's ``configs`` name.
+"""Problem zoo (test, bench and example input -- not part of the product
+package): the direct-collocation problems BASELINE.json's ``configs`` name.
 
 Each factory returns a plain ``dict`` of keyword arguments that both this
 package's :class:`opty_amd.ConstraintCollocator` and the reference's
@@ -17,7 +18,7 @@ import sympy.physics.mechanics as me
 __all__ = ['vyasarayani', 'pendulum_swing_up', 'n_link_cart_pendulum',
            'mass_spring_damper', 'variable_duration_pendulum',
            'chaplygin_sleigh', 'one_equation', 'implicit_known_trajectory',
-           'CONFIGS', 'make_free']
+           'gait_like_pendulum', 'CONFIGS', 'make_free']
 
 
 def vyasarayani(num_nodes=51, duration=50.0, method='backward euler'):
@@ -326,6 +327,68 @@ def odd_block_chain(num_nodes=75, method='backward euler',
                 time_symbol=t, integration_method=method)
 
 
+def gait_like_pendulum(num_links=24, num_nodes=50000, method='backward euler',
+                       speed=1.3):
+    """Config-5-shaped stand-in: what ``examples-gallery/advanced/
+    plot_human_gait.py:100-214`` asks of the path, on a system whose equations
+    can be built here (pygait2d is not vendored):
+
+    * ~50 states for ``num_links=24`` (``n_link_pendulum_on_cart``),
+      **variable duration** (``h`` free, bounds like ``:131``),
+    * an unknown input trajectory (cart force ``F``) and a **known** one
+      (a "hand of god" torque on the last link, ``:118-122``),
+    * smooth **contact-like ``exp`` terms** in the dynamic rows (gait2d's
+      ground contact is a smoothed penalty in the foot's height and speed):
+      ``kc*exp(-cc*q0)`` on the cart and ``kd*exp(-cc*q_k)*u_k`` on three links,
+    * **instance constraints** of the gait example's kinds (``:163-184``): a
+      fixed start, ``q0(T) - speed*q1(T)`` (two atoms, one scaled), periodic
+      two-atom pairs that cross states ``q_a(0) - q_b(T)``, speeds
+      ``u_k(0) - u_k(T)`` and one on the unknown input, all written as integer
+      multiples of ``h``.
+    """
+    from sympy.physics.mechanics.models import n_link_pendulum_on_cart
+    me.dynamicsymbols._t = sm.Symbol('t')
+    kane = n_link_pendulum_on_cart(n=num_links, cart_force=True,
+                                   joint_torques=False)
+    q, u = list(kane.q), list(kane.u)
+    states = kane.q.col_join(kane.u)
+    t = me.dynamicsymbols._t
+    eom = sm.Matrix(kane.mass_matrix_full @ states.diff(t) -
+                    kane.forcing_full)
+    kc, cc, kd = sm.symbols('kc, cc, kd', real=True)
+    Tg = sm.Function('Tg')(t)
+    nq = len(q)
+    eom[nq] += kc*sm.exp(-cc*q[0])
+    for k in sorted({1, nq//2, nq - 1}):
+        eom[nq + k] += kd*sm.exp(-cc*q[k])*u[k]
+    eom[2*nq - 1] -= Tg
+    par_map = {}
+    for s in sorted((s for s in eom.free_symbols if s != t),
+                    key=lambda s: s.name):
+        if s in (kc, cc, kd):
+            continue
+        par_map[s] = 9.81 if s.name == 'g' else 1.0 + 0.01*int(s.name[1:])
+    par_map.update({kc: 0.4, cc: 1.5, kd: 0.25})
+    h = sm.Symbol('h', real=True)
+    N = num_nodes
+    dur = (N - 1)*h
+    F = [f for f in eom.atoms(sm.Function) if f.func.__name__ == 'F'][0]
+    pairs = [(1, min(2, nq - 1)), (min(2, nq - 1), 1)]
+    if nq > 4:
+        pairs += [(3, 4), (4, 3)]
+    inst = [q[0].func(0*h), q[0].func(dur) - speed*q[1].func(dur)]
+    inst += [q[a].func(0*h) - q[b].func(dur) for a, b in pairs]
+    inst += [u[k].func(0*h) - u[k].func(dur) for k in range(min(nq, 5))]
+    inst += [F.func(0*h) - F.func(dur)]
+    return dict(equations_of_motion=eom, state_symbols=tuple(states),
+                num_collocation_nodes=N, node_time_interval=h,
+                known_parameter_map=par_map,
+                known_trajectory_map={
+                    Tg: 0.3*np.sin(np.linspace(0.0, 7.0, N))},
+                instance_constraints=tuple(inst), time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -377,6 +440,15 @@ CONFIGS = {
     'config5_standin_24link_small': (n_link_cart_pendulum,
                                      {'num_links': 24, 'num_nodes': 6,
                                       'variable_duration': True}),
+    # config-5-shaped: variable duration, known + unknown input, exp contact
+    # terms, the gait example's instance constraints
+    'gaitlike_3link_be_small': (gait_like_pendulum,
+                                {'num_links': 3, 'num_nodes': 41}),
+    'gaitlike_3link_mid_small': (gait_like_pendulum,
+                                 {'num_links': 3, 'num_nodes': 38,
+                                  'method': 'midpoint'}),
+    'config5_gaitlike_24link': (gait_like_pendulum, {}),
+    'config5_gaitlike_24link_small': (gait_like_pendulum, {'num_nodes': 6}),
 }
 
 

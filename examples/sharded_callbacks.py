@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 import opty_amd
-from opty_amd import problems
+from examples import problems
 
 
 def main():

@@ -201,11 +201,22 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free,
  *         global_jac + node_begin*P is the contiguous slice
  *         [node_begin*P, node_end*P) of the global node-major vector
  *         (opty/direct_collocation.py:2885-2887).
- * `what` is OPTY_HIP_EVAL_*.  Problems with instance constraints and the CSR
- * layout are not sharded. */
+ * `what` is OPTY_HIP_EVAL_*.  Shards cover the collocation part only: the
+ * instance constraints of a problem that has them are evaluated once, by
+ * whichever rank assembles the vectors, with opty_hip_eval_instance.  The CSR
+ * layout is not sharded. */
 int opty_hip_eval_shard(opty_hip_problem *p, int32_t what, const double *free,
                         double *con, int64_t con_stride, double *jac,
                         int64_t node_begin, int64_t node_end);
+/* The instance-constraint tails from the GLOBAL free vector (device
+ * pointers): the o values that follow the M*(N-1) collocation constraints
+ * (opty/direct_collocation.py:2985-2991) into con_tail[0..o) and the nnz_inst
+ * partials that follow the P*(N-1) block values (:2686-2688, :2253-2282) into
+ * jac_tail[0..nnz_inst); either may be NULL.  What a rank of a node-sharded
+ * problem calls for the tail of the vector it assembles; a no-op for problems
+ * without instance constraints. */
+int opty_hip_eval_instance(opty_hip_problem *p, const double *free,
+                           double *con_tail, double *jac_tail);
 /* opty_hip_time_eval for a shard. */
 int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
                              const double *free, double *con,

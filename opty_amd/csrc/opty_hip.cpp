@@ -267,9 +267,22 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
     return 0;
 }
 
-// what: OPTY_HIP_EVAL_*; device pointers only
+// The instance-constraint tails (opty/direct_collocation.py:2985-2991): `con`
+// / `jac` point at the first of the o values / nnz_inst partials (either may
+// be null).  One lane; reads the global free vector through the atom table.
+int launch_instance(opty_hip_problem *p, const double *free_, double *con_tail,
+                    double *jac_tail) {
+    // opty_inst stores con[M*con_stride + k] and jac[(end - begin)*P + k]
+    return launch(p, p->k_inst, 0, 64, free_, con_tail, jac_tail,
+                  NodeRange{0, 0, 0});
+}
+
+// what: OPTY_HIP_EVAL_*; device pointers only.  `with_inst`: the launch
+// covers the whole problem and the instance tails follow the last node's
+// values (node shards leave them to opty_hip_eval_instance).
 int eval_device(opty_hip_problem *p, int what, const double *free_,
-                double *con, double *jac, const NodeRange &rg) {
+                double *con, double *jac, const NodeRange &rg,
+                bool with_inst) {
     const int S = p->d.jac_wgs_per_block, T = 64*p->d.jac_waves_per_wg;
     if (int rc = order_streams(p)) return rc;
     // Node-invariant sub-expressions: recomputed only when their inputs can
@@ -290,12 +303,12 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
         if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
                             64*p->d.fused_waves_per_wg, free_, con, jac, rg))
             return rc;
-    if (p->d.num_inst > 0) {
-        // only whole-problem evaluations reach this (shards reject instance
-        // constraints): the tails follow the last node's values
-        double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr : con;
-        double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr : jac;
-        if (int rc = launch(p, p->k_inst, 0, 64, free_, c, j, rg)) return rc;
+    if (with_inst && p->d.num_inst > 0) {
+        double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr
+            : con + (long long)p->d.M*rg.con_stride;
+        double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr
+            : jac + (rg.end - rg.begin)*p->P();
+        if (int rc = launch_instance(p, free_, c, j)) return rc;
     }
     return 0;
 }
@@ -307,8 +320,6 @@ int check_shard(const opty_hip_problem *p, int what, const double *free_,
     if (what != OPTY_HIP_EVAL_CON && what != OPTY_HIP_EVAL_JAC &&
         what != OPTY_HIP_EVAL_PAIR && what != OPTY_HIP_EVAL_FUSED)
         return fail("bad evaluation selector %d", what);
-    if (p->d.num_inst > 0)
-        return fail("instance constraints are not node-sharded");
     if (p->d.layout != OPTY_HIP_LAYOUT_COO)
         return fail("the CSR layout is not node-sharded");
     if (node_begin < 0 || node_end < node_begin ||
@@ -343,7 +354,7 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
     if (!free_ || (want_con && !con) || (want_jac && !jac))
         return fail("null buffer");
     if (mem == OPTY_HIP_DEVICE)
-        return eval_device(p, what, free_, con, jac, whole(p));
+        return eval_device(p, what, free_, con, jac, whole(p), true);
     if (mem != OPTY_HIP_HOST) return fail("bad memory kind %d", mem);
     // Host buffers (the cyipopt callback case): stage through device memory.
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
@@ -355,7 +366,7 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
     HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
                            hipMemcpyHostToDevice, p->stream));
     if (int rc = eval_device(p, what, p->d_free, p->d_con, p->d_jac,
-                             whole(p)))
+                             whole(p), true))
         return rc;
     if (want_con)
         HIP_TRY(hipMemcpyAsync(con, p->d_con, p->num_con()*sizeof(double),
@@ -1045,7 +1056,9 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
                                     int64_t *cols, int32_t mem) {
     if (!p) return fail("null handle");
     if (p->d.num_inst > 0)
-        return fail("instance constraints are not node-sharded");
+        return fail("a slab handle cannot carry instance constraints (their "
+                    "free indices are global): use one global handle and "
+                    "opty_hip_jacobian_indices_range");
     if (p->d.layout == OPTY_HIP_LAYOUT_CSR)
         return fail("the CSR layout is not node-sharded");
     return indices_impl(p, N_global, node_offset, p->ncon_nodes(), false,
@@ -1054,7 +1067,7 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
 
 static int time_impl(opty_hip_problem *p, int32_t what, const double *free_,
                      double *con, double *jac, const NodeRange &rg,
-                     int32_t iters, float *ms_per_iter) {
+                     bool with_inst, int32_t iters, float *ms_per_iter) {
     if (!ms_per_iter) return fail("null argument");
     if (iters < 1) return fail("iters must be >= 1");
     if (int rc = use_device(p)) return rc;
@@ -1068,7 +1081,8 @@ static int time_impl(opty_hip_problem *p, int32_t what, const double *free_,
     }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     for (int it = 0; it < iters; ++it)
-        if (int rc = eval_device(p, what, free_, con, jac, rg)) return rc;
+        if (int rc = eval_device(p, what, free_, con, jac, rg, with_inst))
+            return rc;
     HIP_TRY(hipEventRecord(p->ev1, p->stream));
     HIP_TRY(hipEventSynchronize(p->ev1));
     float ms = 0.f;
@@ -1081,7 +1095,8 @@ int opty_hip_time_eval(opty_hip_problem *p, int32_t what, const double *free_,
                        double *con, double *jac, int32_t iters,
                        float *ms_per_iter) {
     if (!p) return fail("null argument");
-    return time_impl(p, what, free_, con, jac, whole(p), iters, ms_per_iter);
+    return time_impl(p, what, free_, con, jac, whole(p), true, iters,
+                     ms_per_iter);
 }
 
 int opty_hip_eval_shard(opty_hip_problem *p, int32_t what, const double *free_,
@@ -1093,7 +1108,18 @@ int opty_hip_eval_shard(opty_hip_problem *p, int32_t what, const double *free_,
     if (int rc = check_ready(p)) return rc;
     if (node_end == node_begin) return 0;
     return eval_device(p, what, free_, con, jac,
-                       NodeRange{node_begin, node_end, con_stride});
+                       NodeRange{node_begin, node_end, con_stride}, false);
+}
+
+int opty_hip_eval_instance(opty_hip_problem *p, const double *free_,
+                           double *con_tail, double *jac_tail) {
+    if (!p) return fail("null handle");
+    if (!free_) return fail("null buffer");
+    if (p->d.num_inst == 0 || (!con_tail && !jac_tail)) return 0;
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    if (int rc = order_streams(p)) return rc;
+    return launch_instance(p, free_, con_tail, jac_tail);
 }
 
 int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
@@ -1104,7 +1130,7 @@ int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
     if (int rc = check_shard(p, what, free_, con, jac, con_stride, node_begin,
                              node_end)) return rc;
     return time_impl(p, what, free_, con, jac,
-                     NodeRange{node_begin, node_end, con_stride}, iters,
+                     NodeRange{node_begin, node_end, con_stride}, false, iters,
                      ms_per_iter);
 }
 

@@ -624,6 +624,28 @@ class ConstraintCollocator(object):
                 # arrays are seen as a difference
                 self._uploaded_trajectories = vals
 
+    @staticmethod
+    def _merge_fixed_free(syms, fixed, free, typ, free_op_vals):
+        """The known (``fixed``: symbol -> float, array or callable of the
+        free vector ``free_op_vals``) and the unknown (``free``: ``(r,)``,
+        ``(N,)`` or ``(q, N)``) values of ``syms`` interleaved in ``syms``
+        order; ``typ`` is ``'par'`` or ``'traj'`` -- the reference's static
+        helper with its signature (``opty/direct_collocation.py:2891-2926``).
+        The evaluation path does not call it: the kernels read the known
+        tables and ``free`` directly, :meth:`_sync_known` keeps the tables
+        current."""
+        merged, taken = [], 0
+        for s in syms:
+            if s in fixed:
+                v = fixed[s]
+                merged.append(v(free_op_vals) if callable(v) else v)
+            elif typ == 'traj' and np.ndim(free) == 1:
+                merged.append(free)
+            else:
+                merged.append(free[taken])
+                taken += 1
+        return np.array(merged)
+
     def sync_known(self):
         """Uploads changed ``known_parameter_map`` / ``known_trajectory_map``
         values now; for callers that evaluate through :attr:`hip` with device
@@ -1086,7 +1108,10 @@ class ShardedProblem(Problem):
     sharded (:class:`opty_amd.sharded.ShardedCollocator`), each rank copies its
     shard of every result over its own PCIe link into host vectors shared by
     all processes (:class:`opty_amd.sharded.ShardedCallbacks`).  Instance
-    constraints and the CSR layout are not sharded.
+    constraints (their tails are evaluated once per call from the global
+    ``free``), known trajectories given as functions of ``free`` and changes of
+    the ROOT's known maps between solves are all supported; the CSR layout is
+    not sharded.
 
     Extra keywords: ``group`` (process group), ``root`` (solver rank),
     ``torch_device`` (default ``cuda:<device>``).

@@ -193,6 +193,7 @@ _SIGNATURES = {
     'opty_hip_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64]),
+    'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
@@ -410,6 +411,13 @@ class HipProblem(object):
         _check(self._lib.opty_hip_eval_shard(
             self._h, what, _ptr(free), _ptr(con), con_stride, _ptr(jac),
             node_begin, node_end))
+
+    def eval_instance(self, free, con_tail, jac_tail):
+        """The instance-constraint values / partials from the global device
+        ``free`` into device buffers (either may be None); see
+        ``opty_hip_eval_instance``."""
+        _check(self._lib.opty_hip_eval_instance(
+            self._h, _ptr(free), _ptr(con_tail), _ptr(jac_tail)))
 
     def time_eval_shard(self, what, free, con, con_stride, jac, node_begin,
                         node_end, iters):

@@ -10,7 +10,7 @@ committed (as ``.npz`` data), together with this script.  ``cyipopt`` is absent
 here; ``stubs/cyipopt.py`` is a ten-line stand-in that lets
 ``opty/direct_collocation.py:10`` import.
 
-For every problem in ``opty_amd.problems.CONFIGS`` that is listed below it
+For every problem in ``examples.problems.CONFIGS`` that is listed below it
 stores: the symbol ordering the reference derived, sizes, the deterministic
 ``free`` recipe (seed) and
 
@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 import numpy as np                                            # noqa: E402
 import sympy as sm                                            # noqa: E402
 from opty.direct_collocation import ConstraintCollocator     # noqa: E402
-from opty_amd import problems                                 # noqa: E402
+from examples import problems                                 # noqa: E402
 
 OUT = os.path.abspath(os.path.join(HERE, '..'))
 
@@ -49,9 +49,10 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'elementary_mid_small', 'delay_be_small', 'delay_mid_small',
          'odd_block_be_small', 'odd_block_mid_small',
          'piecewise_be_small', 'piecewise_mid_small',
-         'states_only_mid_small']
+         'states_only_mid_small', 'gaitlike_3link_be_small',
+         'gaitlike_3link_mid_small', 'config5_gaitlike_24link_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999,
-         'config5_standin_24link': 4999}
+         'config5_standin_24link': 4999, 'config5_gaitlike_24link': 4999}
 
 
 def sample_nodes(num_con_nodes, stride):

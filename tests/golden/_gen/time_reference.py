@@ -26,7 +26,7 @@ sys.path.insert(0, REPO)
 
 import numpy as np                                            # noqa: E402
 from opty.direct_collocation import ConstraintCollocator     # noqa: E402
-from opty_amd import problems                                 # noqa: E402
+from examples import problems                                 # noqa: E402
 from oracle.collocation_oracle import OracleCollocator        # noqa: E402
 
 

@@ -4,7 +4,7 @@ ignored, nothing falls back to a CPU path."""
 import numpy as np
 import pytest
 
-from opty_amd import problems
+from examples import problems
 
 pytestmark = pytest.mark.gpu
 

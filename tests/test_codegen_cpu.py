@@ -14,7 +14,8 @@ import sympy as sm
 
 import golden_util as gu
 import dag_interp
-from opty_amd import problems, ConstraintCollocator, Problem, parse_free
+from opty_amd import ConstraintCollocator, Problem, parse_free
+from examples import problems
 from opty_amd import hip_backend as hb
 from opty_amd.codegen import ir
 from opty_amd.codegen.emit_hip import EmitOptions, emit_module
@@ -515,3 +516,34 @@ def test_strip_count_rules():
     assert _fit_one_round(9, 1, 1563, live_groups=5) == 9
     assert _fit_one_round(9, 1, 100) == 9
     assert _fit_one_round(32, 5, 100, live_groups=16) == 32   # nothing fits
+
+
+def test_merge_fixed_free_static_helper():
+    """``ConstraintCollocator._merge_fixed_free`` with the reference's static
+    signature: the cases of ``opty/tests/test_direct_collocation.py:1337-1400``
+    plus a callable known value (``opty/direct_collocation.py:2916-2917``)."""
+    import sympy as sm
+    merge = ConstraintCollocator._merge_fixed_free
+    free = np.ones(10)
+    m, c, k = sm.symbols('m, c, k')
+    np.testing.assert_allclose(
+        merge((m, c, k), {m: 1.0, c: 2.0}, np.array([3.0]), 'par', free),
+        [1.0, 2.0, 3.0])
+    a, b, c, d = sm.symbols('a, b, c, d')
+    np.testing.assert_allclose(
+        merge((a, b, c, d), {a: 1.0, b: 2.0}, np.array([3.0, 4.0]), 'par',
+              free), [1.0, 2.0, 3.0, 4.0])
+    t = sm.symbols('t')
+    f, k = [g(t) for g in sm.symbols('f, k', cls=sm.Function)]
+    np.testing.assert_allclose(
+        merge((f, k), {f: np.array([1.0, 2.0])}, np.array([3.0, 4.0]),
+              'traj', free), [[1.0, 2.0], [3.0, 4.0]])
+    a, b, c, d = [g(t) for g in sm.symbols('a, b, c, d', cls=sm.Function)]
+    np.testing.assert_allclose(
+        merge([a, b, c, d], {a: np.array([1.0, 2.0]),
+                             b: np.array([3.0, 4.0])},
+              np.array([[5.0, 6.0], [7.0, 8.0]]), 'traj', free),
+        [[1.0, 2.0], [3.0, 4.0], [5.0, 6.0], [7.0, 8.0]])
+    np.testing.assert_allclose(
+        merge([a, b], {a: lambda fr: 2.0*fr[:2]}, np.array([5.0, 6.0]),
+              'traj', free), [[2.0, 2.0], [5.0, 6.0]])

@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse as sp
 
 import golden_util as gu
-from opty_amd import problems
+from examples import problems
 
 pytestmark = pytest.mark.gpu
 

@@ -11,7 +11,8 @@ import re
 import numpy as np
 import pytest
 
-from opty_amd import problems, ConstraintCollocator
+from opty_amd import ConstraintCollocator
+from examples import problems
 from opty_amd.codegen.emit_hip import EmitOptions, emit_module
 
 TS = 65

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
-from opty_amd import problems
+from examples import problems
 
 pytestmark = pytest.mark.gpu
 

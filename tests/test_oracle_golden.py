@@ -9,7 +9,7 @@ import pytest
 import sympy as sm
 
 import golden_util as gu
-from opty_amd import problems
+from examples import problems
 from oracle.collocation_oracle import OracleCollocator, dense_from_coo
 
 

@@ -14,35 +14,87 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from opty_amd import problems
+from examples import problems
 from opty_amd.sharded import (ShardedCollocator, SharedHostVector,
                               partition_nodes, slab_of)
 
 
 class _OracleShard(object):
     """Evaluates constraint nodes [a, b) of the global problem with the
-    oracle built for the (b - a + 1)-node slab problem."""
+    oracle built for the (b - a + 1)-node slab problem (known trajectories
+    sliced to the slab's time nodes; the instance constraints, which refer to
+    global time nodes, are not part of a slab).  ``instance`` evaluates the
+    instance tails with the oracle of the global problem."""
 
-    def __init__(self, kw, a, b):
+    def __init__(self, kw, a, b, sh=None):
         from oracle.collocation_oracle import OracleCollocator
         self.N = kw['num_collocation_nodes']
-        known = {k: np.asarray(v)[a:b + 1]
-                 for k, v in kw.get('known_trajectory_map', {}).items()}
+        self.a, self.b = a, b
+        self.sh = sh                    # set later: reads its known values
+        self.traj_map = kw.get('known_trajectory_map', {})
+        cnt = b - a + 1
+        known = {k: np.zeros(cnt) for k in self.traj_map}
         self.o = OracleCollocator(name='shard', **dict(
-            kw, num_collocation_nodes=b - a + 1, known_trajectory_map=known))
+            kw, num_collocation_nodes=cnt, known_trajectory_map=known,
+            instance_constraints=None))
         self.con = self.o.generate_constraint_function()
         self.jac = self.o.generate_jacobian_function()
         self.rows = self.o.n + self.o.q
-        self.num_free_global = self.o.num_free + self.rows*(self.N -
-                                                            (b - a + 1))
+        self.full = None
+        if kw.get('instance_constraints') is not None:
+            self.full = OracleCollocator(name='shard_full', **kw)
+
+    def _slab_known(self, free):
+        """Known trajectories of the slab's time nodes: the values the
+        sharded object was handed (``set_known``: the callbacks broadcast the
+        root's), else this rank's own map, callables evaluated at the global
+        ``free`` (opty/direct_collocation.py:2916-2917)."""
+        if self.traj_map:
+            vals = self.sh.known_trajectories if self.sh is not None else None
+            if vals is None:
+                vals = [v(free) if callable(v) else v
+                        for v in self.traj_map.values()]
+            for k, v in zip(self.traj_map, np.asarray(vals)):
+                self.o.known_trajectory_map[k] = \
+                    np.asarray(v)[self.a:self.b + 1]
+        if self.sh is not None and self.sh.known_parameters is not None:
+            for k, v in zip(list(self.o.known_parameter_map),
+                            self.sh.known_parameters):
+                self.o.known_parameter_map[k] = float(v)
 
     def __call__(self, free, con2d, jac1d, a, b, what='both'):
-        slab = slab_of(free.numpy(), self.N, self.rows, a, b)
+        assert (a, b) == (self.a, self.b)
+        free = free.numpy()
+        self._slab_known(free)
+        slab = slab_of(free, self.N, self.rows, a, b)
         if what != 'jac':
             con2d.copy_(torch.from_numpy(
                 self.con(slab).reshape(self.o.M, b - a)))
         if what != 'con':
             jac1d.copy_(torch.from_numpy(np.asarray(self.jac(slab))))
+
+    def instance(self, free, con_tail, jac_tail):
+        free = free.numpy()
+        if con_tail is not None:
+            con_tail.copy_(torch.from_numpy(
+                self.full.eval_instance_constraints(free)))
+        if jac_tail is not None:
+            jac_tail.copy_(torch.from_numpy(
+                self.full.eval_instance_constraints_jacobian_values(free)))
+
+
+def _sharded(kw, rank, world):
+    """This rank's ShardedCollocator over oracle evaluators."""
+    N = kw['num_collocation_nodes']
+    a, b = partition_nodes(N - 1, world)[rank]
+    ev = _OracleShard(dict(kw), a, b)
+    # the slab oracle mutates its own copy of the known-parameter map
+    ev.o.known_parameter_map = dict(ev.o.known_parameter_map)
+    sh = ShardedCollocator(evaluator=ev, instance_evaluator=ev.instance,
+                           block_shape=(ev.o.M, ev.o.M*ev.o.C), **kw)
+    ev.sh = sh
+    assert (sh.a, sh.b) == (a, b)
+    return sh, ev
 
 
 def _free_port():
@@ -53,22 +105,16 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, name, N, out):
+def _worker(rank, world, port, name, N, out, seed=7):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         factory, fkw = problems.CONFIGS[name]
         kw = factory(**dict(fkw, num_nodes=N))
-        a, b = partition_nodes(N - 1, world)[rank]
-        ev = _OracleShard(kw, a, b)
-        sh = ShardedCollocator(evaluator=ev, block_shape=(ev.o.M,
-                                                          ev.o.M*ev.o.C),
-                               **kw)
-        sh.set_num_free(ev.num_free_global)
-        assert (sh.a, sh.b) == (a, b)
+        sh, ev = _sharded(kw, rank, world)
         free = torch.from_numpy(problems.make_free(
-            ev.num_free_global, seed=7,
+            sh.collocator.num_free, seed=seed,
             variable_duration=ev.o.variable_duration))
         # rank 0 holds `free`; the others receive it (RCCL broadcast on GPUs)
         if rank != 0:
@@ -84,14 +130,15 @@ def _worker(rank, world, port, name, N, out):
         sh.evaluate(free)
         a_con, a_jac = sh.all_gather()
         # (3) every rank writes its shard into the node-wide host vectors
-        ncn = N - 1
-        con_host = SharedHostVector('opty_t_con_%d' % port, sh.M*ncn, rank,
-                                    pin=False)
-        jac_host = SharedHostVector('opty_t_jac_%d' % port, sh.P*ncn, rank,
+        con_host = SharedHostVector('opty_t_con_%d' % port,
+                                    sh.num_constraints, rank, pin=False)
+        jac_host = SharedHostVector('opty_t_jac_%d' % port, sh.nnz, rank,
                                     pin=False)
         sh.to_host(con_host, jac_host)
         dist.barrier()
+        irows, icols = sh.instance_indices()
         np.savez(out % rank, a_con=a_con.numpy(), a_jac=a_jac.numpy(),
+                 irows=irows, icols=icols,
                  free=free.numpy(), h_con=np.array(con_host.array),
                  h_jac=np.array(jac_host.array),
                  **({'g_con': g_con.numpy(), 'g_jac': g_jac.numpy()}
@@ -103,12 +150,26 @@ def _worker(rank, world, port, name, N, out):
 @pytest.mark.parametrize('name,N,world', [
     ('msd_be_small', 24, 2),                        # 23 nodes: 12 + 11
     ('pend3_link_midpoint_small', 32, 2),
-    ('pend2_link_vardur_unkmass_small', 26, 3)])    # 25 nodes: 9 + 8 + 8
+    ('pend2_link_vardur_unkmass_small', 26, 3),     # 25 nodes: 9 + 8 + 8
+    # instance constraints (boundary conditions, two-atom periodic pairs, an
+    # input atom), a known trajectory, variable duration, exp terms: the
+    # config-5-shaped problem at its golden sizes
+    ('gaitlike_3link_mid_small', 38, 2),            # 37 nodes: 19 + 18
+    ('gaitlike_3link_be_small', 41, 3),             # 40 nodes: 14 + 13 + 13
+    ('chaplygin_be_small', 100, 2),                 # M > n, 8 instance cons
+    # known trajectories given as functions of free
+    ('implicit_traj_be_small', 40, 2),              # 39 nodes: 20 + 19
+    ('implicit_traj_mid_small', 33, 3)])            # 32 nodes: 11 + 11 + 10
 def test_shards_reassemble_to_full(tmp_path, name, N, world):
     from oracle.collocation_oracle import OracleCollocator
+    import golden_util as gu
     assert (N - 1) % world != 0, 'the test wants unequal shards'
     out = str(tmp_path/'rank%d.npz')
-    mp.spawn(_worker, args=(world, _free_port(), name, N, out),
+    golden = None
+    if name in gu.MANIFEST and gu.MANIFEST[name]['N'] == N:
+        golden = gu.load(name)
+    seed = golden[0]['seed'] if golden else 7
+    mp.spawn(_worker, args=(world, _free_port(), name, N, out, seed),
              nprocs=world, join=True)
     factory, fkw = problems.CONFIGS[name]
     full = OracleCollocator(name='shard', **factory(**dict(fkw,
@@ -117,6 +178,7 @@ def test_shards_reassemble_to_full(tmp_path, name, N, world):
     free = z[0]['free']
     c_ref = full.generate_constraint_function()(free)
     j_ref = np.asarray(full.generate_jacobian_function()(free))
+    assert len(c_ref) == full.num_constraints       # tails included
     kw = dict(rtol=1e-13, atol=1e-13)
     for r in range(world):
         np.testing.assert_array_equal(z[r]['free'], free)   # broadcast
@@ -127,6 +189,22 @@ def test_shards_reassemble_to_full(tmp_path, name, N, world):
         assert ('g_con' in z[r].files) == (r == world - 1)
     np.testing.assert_allclose(z[world - 1]['g_con'], c_ref, **kw)
     np.testing.assert_allclose(z[world - 1]['g_jac'], j_ref, **kw)
+    if golden:
+        # ... and to what the REFERENCE returned for this problem: values,
+        # instance tails, int64 indices of the tail
+        meta, g = golden
+        np.testing.assert_array_equal(g['free'], free)
+        for r in range(world):
+            np.testing.assert_allclose(z[r]['h_con'], g['con'], rtol=1e-10,
+                                       atol=1e-9)
+            np.testing.assert_allclose(z[r]['h_jac'], g['jac'], rtol=1e-10,
+                                       atol=1e-9)
+            nz = meta['nnz_inst']
+            assert z[r]['irows'].dtype == np.int64
+            np.testing.assert_array_equal(z[r]['irows'],
+                                          g['rows'][len(g['rows']) - nz:])
+            np.testing.assert_array_equal(z[r]['icols'],
+                                          g['cols'][len(g['cols']) - nz:])
 
 
 def _callback_worker(rank, world, port, name, N, out):
@@ -137,46 +215,61 @@ def _callback_worker(rank, world, port, name, N, out):
     try:
         factory, fkw = problems.CONFIGS[name]
         kw = factory(**dict(fkw, num_nodes=N))
-        a, b = partition_nodes(N - 1, world)[rank]
-        ev = _OracleShard(kw, a, b)
-        sh = ShardedCollocator(evaluator=ev, block_shape=(ev.o.M,
-                                                          ev.o.M*ev.o.C),
-                               **kw)
-        sh.set_num_free(ev.num_free_global)
+        sh, ev = _sharded(kw, rank, world)
         cb = ShardedCallbacks(sh, name='opty_t_cb_%d' % port, root=1)
         if rank != 1:
             cb.serve()                  # returns after the root's shutdown
             return
-        frees = [problems.make_free(ev.num_free_global, seed=s,
+        frees = [problems.make_free(sh.collocator.num_free, seed=s,
                                     variable_duration=ev.o.variable_duration)
                  for s in (1, 2, 3)]
         c1 = cb.constraints(frees[0])
         j1 = cb.jacobian(frees[0]).copy()
         c2 = cb.constraints(frees[1])               # line search: con only
         c3, j3 = cb.constraints_and_jacobian(frees[2])
+        j3 = j3.copy()          # the persistent buffer (:2814)
         with pytest.raises(ValueError):
             cb.constraints(frees[0][:-1])
+        extra = {}
+        pm = kw['known_parameter_map']
+        if pm:
+            # the solver's process changes a known parameter between solves
+            # (plot_human_gait.py): every rank must evaluate with the new
+            # value, the serving ranks' own maps notwithstanding
+            key = list(pm)[-1]
+            pm[key] = 1.75*float(pm[key]) + 0.125
+            tm = kw.get('known_trajectory_map', {})
+            for k, v in tm.items():
+                if not callable(v):
+                    tm[k] = np.asarray(v)*0.5 + 0.25
+            c4, j4 = cb.constraints_and_jacobian(frees[0])
+            extra = dict(c4=c4, j4=j4.copy(), p4=np.array(
+                [float(v) for v in pm.values()]))
         np.savez(out, f1=frees[0], f2=frees[1], f3=frees[2], c1=c1, j1=j1,
-                 c2=c2, c3=c3, j3=j3.copy())
+                 c2=c2, c3=c3, j3=j3, **extra)
         cb.shutdown()
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize('name,N,world', [
-    ('msd_be_small', 24, 2), ('pend2_link_vardur_unkmass_small', 26, 3)])
+    ('msd_be_small', 24, 2), ('pend2_link_vardur_unkmass_small', 26, 3),
+    ('gaitlike_3link_be_small', 41, 3), ('implicit_traj_be_small', 40, 2),
+    ('config2_pendulum_small', 101, 3)])
 def test_callbacks_served_by_all_ranks(tmp_path, name, N, world):
     """``ShardedCallbacks``: the solver's rank (here rank 1) gets
-    ``constraints(free)`` / ``jacobian(free)`` of the whole problem through
-    the shared host vectors while the other ranks serve."""
+    ``constraints(free)`` / ``jacobian(free)`` of the whole problem --
+    instance constraints, callable known trajectories and known-map changes
+    between calls included -- through the shared host vectors while the other
+    ranks serve."""
     from oracle.collocation_oracle import OracleCollocator
     out = str(tmp_path/'root.npz')
     mp.spawn(_callback_worker, args=(world, _free_port(), name, N, out),
              nprocs=world, join=True)
     z = np.load(out)
     factory, fkw = problems.CONFIGS[name]
-    full = OracleCollocator(name='shard', **factory(**dict(fkw,
-                                                           num_nodes=N)))
+    pkw = factory(**dict(fkw, num_nodes=N))
+    full = OracleCollocator(name='shard', **pkw)
     con, jac = (full.generate_constraint_function(),
                 full.generate_jacobian_function())
     kw = dict(rtol=1e-13, atol=1e-13)
@@ -185,6 +278,18 @@ def test_callbacks_served_by_all_ranks(tmp_path, name, N, world):
     np.testing.assert_allclose(z['c2'], con(z['f2']), **kw)
     np.testing.assert_allclose(z['c3'], con(z['f3']), **kw)
     np.testing.assert_allclose(z['j3'], jac(z['f3']), **kw)
+    if 'c4' in z.files:
+        before = con(z['f1'])
+        for k, v in zip(list(pkw['known_parameter_map']), z['p4']):
+            full.known_parameter_map[k] = float(v)
+        tm = full.known_trajectory_map
+        for k, v in tm.items():
+            if not callable(v):
+                tm[k] = np.asarray(v)*0.5 + 0.25
+        after = con(z['f1'])
+        assert not np.allclose(before, after)       # the change matters
+        np.testing.assert_allclose(z['c4'], after, **kw)
+        np.testing.assert_allclose(z['j4'], jac(z['f1']), **kw)
 
 
 def test_partition():
@@ -201,10 +306,15 @@ def test_slab_is_a_collocation_problem():
     np.testing.assert_array_equal(slab, want)
 
 
-def test_csr_and_instance_constraints_are_rejected():
+def test_csr_is_rejected_instance_constraints_are_not():
     kw = problems.build('config2_pendulum_small')
-    with pytest.raises(NotImplementedError):
-        ShardedCollocator(rank=0, world_size=2, **kw)
+    sh = ShardedCollocator(rank=1, world_size=2, evaluator=lambda *a: None,
+                           instance_evaluator=lambda *a: None, **kw)
+    assert (sh.o, sh.nnz_inst) == (4, 4) and sh.tail_rank == 1
+    assert sh.num_constraints == sh.collocator.num_constraints
+    with pytest.raises(ValueError):         # no instance evaluator given
+        ShardedCollocator(rank=0, world_size=2, evaluator=lambda *a: None,
+                          **kw)
     kw = problems.build('msd_be_small')
     with pytest.raises(NotImplementedError):
         ShardedCollocator(rank=0, world_size=2, jacobian_layout='csr', **kw)

@@ -12,7 +12,7 @@ import pytest
 import sympy as sm
 
 import golden_util as gu
-from opty_amd import problems
+from examples import problems
 from opty_amd.utils import coo_to_dense
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',

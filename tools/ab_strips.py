@@ -17,7 +17,8 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 import numpy as np                                            # noqa: E402
 import torch                                                  # noqa: E402
 import opty_amd                                               # noqa: E402
-from opty_amd import problems, hip_backend as hb              # noqa: E402
+from opty_amd import hip_backend as hb              # noqa: E402
+from examples import problems
 from opty_amd.codegen.emit_hip import EmitOptions             # noqa: E402
 from tune_jac import parse                                    # noqa: E402
 

@@ -18,7 +18,7 @@ sys.path.insert(0, REPO)
 
 import numpy as np                                            # noqa: E402
 import opty_amd                                               # noqa: E402
-from opty_amd import problems                                 # noqa: E402
+from examples import problems                                 # noqa: E402
 
 
 def main():

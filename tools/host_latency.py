@@ -8,7 +8,8 @@ sys.path.insert(0, REPO)
 import numpy as np
 import torch
 import opty_amd
-from opty_amd import problems, hip_backend as hb
+from opty_amd import hip_backend as hb
+from examples import problems
 col = opty_amd.ConstraintCollocator(**problems.build('config2_pendulum'))
 hip = col.hip
 cf, jf = col.generate_constraint_function(), col.generate_jacobian_function()

@@ -6,7 +6,7 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 import numpy as np
 import opty_amd
-from opty_amd import problems
+from examples import problems
 col = opty_amd.ConstraintCollocator(**problems.build('config3_10link'))
 con = col.generate_constraint_function()
 jac = col.generate_jacobian_function()

@@ -7,7 +7,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 import torch
 import opty_amd
-from opty_amd import problems, hip_backend as hb
+from opty_amd import hip_backend as hb
+from examples import problems
 col = opty_amd.ConstraintCollocator(**problems.build('config3_10link_small'))
 hip = col.hip
 dev = torch.device('cuda:0')

@@ -21,7 +21,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 
 import numpy as np                                            # noqa: E402
-from opty_amd import hip_backend as hb, problems              # noqa: E402
+from opty_amd import hip_backend as hb              # noqa: E402
+from examples import problems              # noqa: E402
 
 HERE = os.path.join(REPO, 'tools', 'o3_repro')
 NAME = 'o3_repro_24link_csr_row47'

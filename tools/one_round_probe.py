@@ -8,7 +8,8 @@ sys.path.insert(0, REPO)
 import numpy as np
 import torch
 import opty_amd
-from opty_amd import problems, hip_backend as hb
+from opty_amd import hip_backend as hb
+from examples import problems
 from opty_amd.codegen.emit_hip import EmitOptions
 groups = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 factory, fkw = problems.CONFIGS['config3_10link']

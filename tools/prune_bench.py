@@ -6,7 +6,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 import numpy as np, torch
 import opty_amd
-from opty_amd import problems, hip_backend as hb
+from opty_amd import hip_backend as hb
+from examples import problems
 for prune in (False, True):
     col = opty_amd.ConstraintCollocator(prune_zeros=prune, **problems.build('config3_10link'))
     hip = col.hip

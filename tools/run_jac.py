@@ -5,7 +5,8 @@ REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
 import torch
 import opty_amd
-from opty_amd import problems, hip_backend as hb
+from opty_amd import hip_backend as hb
+from examples import problems
 from tune_jac import parse
 from opty_amd.codegen.emit_hip import EmitOptions
 spec = sys.argv[1] if len(sys.argv) > 1 else 'default'
