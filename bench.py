@@ -278,6 +278,95 @@ def host_path(kw, dev_index, reps=7):
     return out
 
 
+class _Verifier(object):
+    """Checks outputs of the benched launches against the REFERENCE's golden
+    record of this workload (``tests/golden/config3_10link.npz``: full blocks
+    at a strided node sample, per-entry / per-equation sums over ALL nodes,
+    recorded from csu-hmc/opty's compiled path by
+    ``tests/golden/_gen/make_golden.py``; ``frees[0]`` is its seed-0 vector).
+    Runs after the timed region, never inside it.
+
+    Tolerance: 1e-10 relative per sampled entry, an entry that cancels to
+    (nearly) nothing being held to 1e-10 of the largest entry of its own
+    equation row at its own node; sums to 1e-9 of the mean absolute entry
+    times the node count."""
+
+    def __init__(self, M, P, N, dev):
+        import numpy as np
+        with open(os.path.join(REPO, 'tests', 'golden',
+                               'MANIFEST.json')) as f:
+            self.meta = json.load(f)[WORKLOAD]
+        self.z = np.load(os.path.join(REPO, 'tests', 'golden',
+                                      WORKLOAD + '.npz'))
+        assert (self.meta['N'], self.meta['M'], self.meta['M'] *
+                self.meta['C']) == (N, M, P)
+        self.M, self.P, self.N, self.dev = M, P, N, dev
+        self.C = P//M
+        self.worst = 0.0
+        self.failed = []
+        self.checked = []
+
+    def _entries(self, got, want, rowmax, label):
+        import numpy as np
+        err = np.abs(got - want)
+        ref = np.maximum(np.abs(want), rowmax)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            rel = np.where(ref > 0, err/ref, err)
+        worst = float(np.nanmax(rel)) if rel.size else 0.0
+        if not np.isfinite(got).all():
+            worst = float('inf')
+        self.worst = max(self.worst, worst)
+        if not worst <= 1e-10:
+            self.failed.append('%s: worst relative error %.3g' % (label,
+                                                                  worst))
+
+    def nodes(self, con2d, jac2d, a, b, label):
+        """``con2d`` (M, b-a) / ``jac2d`` (b-a, P) tensors or arrays of the
+        constraint nodes [a, b): the reference's sampled nodes among them."""
+        import numpy as np
+        import torch
+        nodes = self.z['nodes']
+        pick = (nodes >= a) & (nodes < b)
+        sel = nodes[pick] - a
+        if not len(sel):
+            return
+        want_j = self.z['jac_nodes'][pick]
+        rowmax = np.abs(want_j.reshape(len(sel), self.M, self.C)).max(axis=2)
+        if torch.is_tensor(jac2d):
+            idx = torch.from_numpy(sel).to(jac2d.device)
+            got_j = jac2d[idx].cpu().numpy()
+            got_c = con2d[:, idx].cpu().numpy()
+        else:
+            got_j, got_c = jac2d[sel], con2d[:, sel]
+        self._entries(got_j, want_j, np.repeat(rowmax, self.C, axis=1),
+                      label + ' jac nodes')
+        self._entries(got_c, self.z['con_nodes'][:, pick], rowmax.T,
+                      label + ' con nodes')
+        self.checked.append('%s: %d sampled nodes' % (label, len(sel)))
+
+    def sums(self, jac_sum, con_sum, jac_abs, con_abs, label):
+        """Sums over ALL constraint nodes (already reduced over the ranks):
+        per block entry (P,), per equation (M,), of |jac| and of |con| (the
+        scale of the constraint sums)."""
+        import numpy as np
+        scale = float(self.z['jac_abs_sum'][0])
+        for got, want, ref, tag in (
+                (jac_sum, self.z['jac_entry_sums'], scale/self.P,
+                 'jac entry sums'),
+                (con_sum, self.z['con_eq_sums'], float(con_abs)/self.M,
+                 'con sums'),
+                (np.array([jac_abs]), self.z['jac_abs_sum'], scale,
+                 'jac abs sum')):
+            got = np.asarray(got, dtype=float)
+            rel = np.abs(got - want)/np.maximum(np.abs(want), ref)
+            worst = float(np.nanmax(rel)) if np.isfinite(got).all() \
+                else float('inf')
+            self.worst = max(self.worst, worst*0.1)     # bar is 1e-9
+            if not worst <= 1e-9:
+                self.failed.append('%s %s: %.3g' % (label, tag, worst))
+        self.checked.append(label + ': checksums over all nodes')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -407,6 +496,41 @@ def main():
                                    b, args.steps)
     barrier()
 
+    # ---- verification of what was benched (after the timed region) ----------
+    # frees[0] is the seed-0 vector the reference's golden record of this
+    # workload was made with; the check runs the very launch that was timed.
+    verifier = None
+    verify = {'ok': None, 'skipped': 'no reference golden for N = %d'
+              % args.nodes}
+    if args.nodes == 100000:
+        verifier = _Verifier(M, P, N, dev)
+
+    def reduce_sum(t):
+        if world > 1 and strong:
+            if oversub:
+                h = t.cpu()
+                dist.all_reduce(h)
+                return h
+            dist.all_reduce(t)
+        return t.cpu()
+
+    def check_sums(con2d, jac2d, label, reduce=True):
+        part = torch.cat([jac2d.sum(0), con2d.sum(1),
+                          jac2d.abs().sum().view(1),
+                          con2d.abs().sum().view(1)])
+        part = (reduce_sum(part) if reduce else part.cpu()).numpy()
+        verifier.sums(part[:P], part[P:P + M], part[P + M], part[P + M + 1],
+                      label)
+
+    if verifier is not None:
+        step(0)
+        torch.cuda.synchronize()
+        jac2d = jac.view(b - a, P)
+        if strong or rank == 0:
+            verifier.nodes(con, jac2d, a, b, 'benched launch')
+        if strong or world == 1:
+            check_sums(con, jac2d, 'benched launch')
+
     extras = {}
     if not args.no_extras:
         if not args.serial:
@@ -424,6 +548,14 @@ def main():
                     sh.evaluate(frees[k % 4], in_place=(rank == 0))
                     sh.gather(0)
                 el = timed(gather_step, args.steps, args.warmup)
+                if verifier is not None:
+                    sh.evaluate(frees[0], in_place=(rank == 0))
+                    got = sh.gather(0)
+                    if rank == 0:
+                        gc = got[0][:M*ncn].view(M, ncn)
+                        gj = got[1][:P*ncn].view(ncn, P)
+                        verifier.nodes(gc, gj, 0, ncn, 'gather')
+                        check_sums(gc, gj, 'gather', reduce=False)
                 variants['gather'] = {
                     'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
                     'what': 'eval + point-to-point gather-v of con and jac to '
@@ -447,6 +579,20 @@ def main():
                         sh.evaluate(frees[k % 4])
                         sh.to_host(con_host, jac_host)
                     el = timed(host_step, args.steps, args.warmup)
+
+                    def check_host(cvec, jvec, label):
+                        hc = torch.from_numpy(cvec[:M*ncn]).view(M, ncn)
+                        hj = torch.from_numpy(jvec[:P*ncn]).view(ncn, P)
+                        verifier.nodes(hc.numpy(), hj.numpy(), 0, ncn, label)
+                        check_sums(hc, hj, label, reduce=False)
+                    if verifier is not None:
+                        con_host.array[:] = float('nan')
+                        barrier()
+                        host_step(0)
+                        barrier()
+                        if rank == 0:
+                            check_host(con_host.array, jac_host.array,
+                                       'to_host')
                     variants['to_host'] = {
                         'evals_per_s': args.steps/el,
                         'ms_per_step': 1e3*el/args.steps,
@@ -462,7 +608,9 @@ def main():
                                           os.getppid(), jac_host=jac_host)
                     if rank == 0:
                         hf = [f.cpu().numpy() for f in frees[:2]]
-                        cb.constraints(hf[0]), cb.jacobian(hf[0])
+                        c0, j0 = cb.constraints(hf[0]), cb.jacobian(hf[0])
+                        if verifier is not None:
+                            check_host(c0, j0, 'callbacks')
                         reps = max(5, args.steps//10)
                         t0 = time.perf_counter()
                         for k in range(reps):
@@ -492,6 +640,23 @@ def main():
             extras['other_configs'] = other_configs(dev, max(20,
                                                              args.steps//4))
             extras['host_path_ms'] = host_path(kw, local_rank)
+
+    if verifier is not None:
+        # every rank's verdict: worst error and number of failed checks
+        st = torch.tensor([verifier.worst if verifier.worst == verifier.worst
+                           else float('inf'), float(len(verifier.failed))],
+                          dtype=torch.float64)
+        if world > 1:
+            st = st.to(dev) if not oversub else st
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            st = st.cpu()
+        verify = {
+            'ok': bool(st[1].item() == 0 and st[0].item() <= 1e-10),
+            'worst_rel': st[0].item(), 'ranks': world,
+            'backend': (dist.get_backend() if world > 1 else None),
+            'golden': 'tests/golden/%s.npz (reference: %s)' % (
+                WORKLOAD, verifier.meta['reference']),
+            'checked': verifier.checked, 'failed': verifier.failed}
 
     if rank == 0:
         cnt = b - a
@@ -558,11 +723,16 @@ def main():
                 'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
         }
         out['config'].update(extras)
+        out['config']['verify'] = verify
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(kw)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if verify['ok'] is False:
+        # a fast launch whose results differ from the reference's is not a
+        # result: the line above carries the details
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -14,7 +14,7 @@ FULL = sorted(k for k, v in MANIFEST.items() if v['kind'] == 'full')
 #: fixtures whose ORACLE takes minutes to build (SymPy differentiating a
 #: 24-link pendulum); the oracle was checked against them once in the build
 #: container (5e-16), the product is checked against them in every run.
-HEAVY = {'config5_standin_24link_small'}
+HEAVY = {'config5_standin_24link_small', 'config5_gaitlike_24link_small'}
 FULL_FAST = [k for k in FULL if k not in HEAVY]
 SAMPLED = sorted(k for k, v in MANIFEST.items() if v['kind'] == 'sampled')
 

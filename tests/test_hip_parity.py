@@ -95,6 +95,27 @@ def test_golden_sampled(name):
                     bound=ijb)
     np.testing.assert_array_equal(rows[P*(N - 1):], z['rows_tail'])
     np.testing.assert_array_equal(cols[P*(N - 1):], z['cols_tail'])
+    # the FUSED launch over the whole problem (what bench.py times; its
+    # expressions are scheduled on their own): same record
+    from opty_amd import hip_backend as hb
+    con2 = np.empty_like(con)
+    jac2 = hb.pinned_empty(len(jac))
+    col.hip.eval_con_jac(free, con2, jac2, hb.HOST)
+    blk2 = jac2[:P*(N - 1)].reshape(N - 1, P)
+    cb2 = con2[:M*(N - 1)].reshape(M, N - 1)
+    gu.assert_close(blk2[nodes], z['jac_nodes'], RTOL,
+                    what=name + ' fused jac nodes', bound=jbn,
+                    cap=jcap.reshape(len(nodes), P))
+    gu.assert_close(cb2[:, nodes], z['con_nodes'], RTOL,
+                    what=name + ' fused con nodes', bound=cbn, cap=ccap)
+    gu.assert_close(blk2.sum(axis=0), z['jac_entry_sums'], 1e-9,
+                    scale=scale/P, what='fused jac entry sums')
+    gu.assert_close(cb2.sum(axis=1), z['con_eq_sums'], 1e-9,
+                    scale=float(np.abs(cb2).sum())/M, what='fused con sums')
+    gu.assert_close(con2[M*(N - 1):], z['con_tail'], RTOL,
+                    what='fused con tail', bound=icb)
+    gu.assert_close(jac2[P*(N - 1):], z['jac_tail'], RTOL,
+                    what='fused jac tail', bound=ijb)
 
 
 @pytest.mark.parametrize('name,N', [

@@ -127,6 +127,103 @@ def test_one_of_eight_shards_against_the_reference(rank):
         cols.reshape(-1, P)[sel - sh.a], z['cols_nodes'][pick])
 
 
+@pytest.mark.parametrize('name', ['config2_pendulum_small',
+                                  'gaitlike_3link_be_small',
+                                  'gaitlike_3link_mid_small',
+                                  'chaplygin_mid_small', 'delay_be_small'])
+def test_instance_tails_next_to_node_ranges(name):
+    """A problem WITH instance constraints evaluated as node ranges
+    (``opty_hip_eval_shard``: collocation part only) plus
+    ``opty_hip_eval_instance`` for the tails gives bit for bit what the
+    whole-problem launch gives, and the reference's golden values."""
+    import torch
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    meta, z = gu.load(name)
+    col = opty_amd.ConstraintCollocator(**problems.build(name))
+    hip = col.hip
+    dev = torch.device('cuda:0')
+    hip.use_torch_stream()
+    M, P, ncn = meta['M'], meta['M']*meta['C'], meta['N'] - 1
+    free = torch.from_numpy(z['free']).to(dev)
+    con = torch.empty(col.num_constraints, dtype=torch.float64, device=dev)
+    jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+    hip.eval_con_jac(free, con, jac, hb.DEVICE)
+    con2 = torch.full_like(con, np.nan)
+    jac2 = torch.full_like(jac, np.nan)
+    cuts = [0, ncn//3, ncn//3 + 1, ncn]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        hip.eval_shard(hb.EVAL_FUSED, free, con2[a:], ncn, jac2[a*P:], a, b)
+    assert torch.isnan(con2[M*ncn:]).all() and torch.isnan(jac2[P*ncn:]).all()
+    hip.eval_instance(free, con2[M*ncn:], jac2[P*ncn:])
+    torch.cuda.synchronize()
+    assert torch.equal(con, con2) and torch.equal(jac, jac2)
+    # either tail alone
+    con3 = torch.full((meta['o'],), np.nan, dtype=torch.float64, device=dev)
+    hip.eval_instance(free, con3, None)
+    jac3 = torch.full((meta['nnz_inst'],), np.nan, dtype=torch.float64,
+                      device=dev)
+    hip.eval_instance(free, None, jac3)
+    torch.cuda.synchronize()
+    assert torch.equal(con3, con[M*ncn:]) and torch.equal(jac3, jac[P*ncn:])
+    cb, jb = gu.error_bounds(col, z['free'])
+    gu.assert_close(con2.cpu().numpy(), z['con'], RTOL,
+                    what=name + ' ranges+tails con', bound=cb)
+    gu.assert_close(jac2.cpu().numpy(), z['jac'], RTOL,
+                    what=name + ' ranges+tails jac', bound=jb)
+    hip.set_stream(None)
+
+
+@pytest.mark.parametrize('name,rank', [('config5_standin_24link', 0),
+                                       ('config5_standin_24link', 7),
+                                       ('config5_gaitlike_24link', 0),
+                                       ('config5_gaitlike_24link', 4),
+                                       ('config5_gaitlike_24link', 7)])
+def test_one_of_eight_shards_of_the_config5_stand_ins(name, rank):
+    """A 6 250-node shard (world size 8) of the 50-state, variable-duration
+    stand-ins at N = 50 000 against the reference's sampled nodes; for the
+    gait-like one (known trajectory, exp terms, 12 instance constraints) also
+    the instance tails, which the assembling rank evaluates from the global
+    free vector, and the int64 indices of shard and tail."""
+    import torch
+    from opty_amd.sharded import ShardedCollocator
+    meta, z = gu.load(name)
+    N, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    sh = ShardedCollocator(rank=rank, world_size=8, **problems.build(name))
+    assert (sh.o, sh.nnz_inst) == (meta['o'], meta['nnz_inst'])
+    free = problems.make_free(sh.collocator.num_free, seed=meta['seed'],
+                              variable_duration=True)
+    dfree = torch.from_numpy(free).cuda()
+    con, jac = sh.evaluate(dfree)
+    ic, ij = sh.evaluate_instance()
+    torch.cuda.synchronize()
+    con, jac = con.cpu().numpy(), jac.cpu().numpy().reshape(-1, P)
+    nodes = z['nodes']
+    pick = (nodes >= sh.a) & (nodes < sh.b)
+    assert pick.sum() >= 1
+    sel = nodes[pick]
+    cbn, jbn, icb, ijb = gu.error_bounds(sh.collocator, free, sel)
+    gu.assert_close(jac[sel - sh.a], z['jac_nodes'][pick], RTOL,
+                    what=name + ' 1/8 shard jac nodes', bound=jbn)
+    gu.assert_close(con[:, sel - sh.a], z['con_nodes'][:, pick], RTOL,
+                    what=name + ' 1/8 shard con nodes', bound=cbn)
+    assert np.isfinite(jac).all() and np.abs(jac).sum(axis=1).min() > 0
+    rows, cols = sh.jacobian_indices_local()
+    np.testing.assert_array_equal(
+        rows.reshape(-1, P)[sel - sh.a], z['rows_nodes'][pick])
+    np.testing.assert_array_equal(
+        cols.reshape(-1, P)[sel - sh.a], z['cols_nodes'][pick])
+    if meta['o']:
+        gu.assert_close(ic.cpu().numpy(), z['con_tail'], RTOL,
+                        what=name + ' shard con tail', bound=icb)
+        gu.assert_close(ij.cpu().numpy(), z['jac_tail'], RTOL,
+                        what=name + ' shard jac tail', bound=ijb)
+        irows, icols = sh.instance_indices()
+        np.testing.assert_array_equal(irows, z['rows_tail'])
+        np.testing.assert_array_equal(icols, z['cols_tail'])
+
+
 def _worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
@@ -235,6 +332,32 @@ def test_bench_strong_scaling_two_ranks():
                                               'callbacks'}
     assert res['config']['variants']['callbacks']['evals_per_s'] > 0
     assert res['value'] > 0 and res['roofline']['frac'] > 0
+    # the line certifies itself: the benched launches of both ranks and every
+    # re-assembly variant were checked against the reference's golden record
+    ver = res['config']['verify']
+    assert ver['ok'] is True and ver['ranks'] == 2, ver
+    assert ver['worst_rel'] <= 1e-10
+    labels = ' '.join(ver['checked'])
+    for tag in ('benched launch', 'gather', 'to_host', 'callbacks'):
+        assert tag in labels, ver
+
+
+def test_bench_single_gpu_line_verifies_itself():
+    """``bench.py`` as the driver runs it at N = 1: the JSON line carries
+    ``config.verify.ok`` from checking the timed launch against the
+    reference's golden record, and the exit code is 0."""
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '5',
+           '--warmup', '2', '--prewarm-ms', '20', '--no-cpu-baseline',
+           '--no-extras']
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO,
+                          timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines()
+                      if ln.startswith('{')][-1])
+    ver = res['config']['verify']
+    assert ver['ok'] is True and ver['worst_rel'] <= 1e-10, ver
+    assert any('checksums over all nodes' in c for c in ver['checked'])
+    assert any('sampled nodes' in c for c in ver['checked'])
 
 
 def _problem_worker(rank, world, port, out):
@@ -318,6 +441,103 @@ def test_sharded_problem_callbacks_from_two_ranks(tmp_path):
     gu.assert_close(z['c2'], con(z['f1']), 1e-12,
                     what='sharded problem con 2', bound=cb)
     assert np.isfinite(z['obj'][0])
+
+
+def _config2_worker(rank, world, port, out, backend):
+    import sys
+    import types
+    import torch
+    import torch.distributed as dist
+    import opty_amd
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    kw = dict(rank=rank, world_size=world)
+    if backend == 'nccl':
+        kw['device_id'] = torch.device('cuda', 0)
+    dist.init_process_group(backend, **kw)
+    try:
+        torch.cuda.set_device(0)
+        pkw = problems.build('config2_pendulum')
+        prob = opty_amd.ShardedProblem(lambda f: 0.0, lambda f: 0.0*f, **pkw)
+        assert prob.sharded.o == 4 and prob.callbacks._rccl == (
+            backend == 'nccl')
+        if rank != 0:
+            prob.serve()
+            return
+        meta, _ = gu.load('config2_pendulum')
+        free = problems.make_free(prob.num_free, seed=meta['seed'])
+        con = prob.constraints(free)
+        jac = np.array(prob.jacobian(free))
+        rows, cols = prob.jacobianstructure()
+        # the solver changes a known parameter between solves
+        # (plot_human_gait.py): the serving ranks follow
+        g = [k for k in pkw['known_parameter_map'] if str(k) == 'g'][0]
+        prob.collocator.known_parameter_map[g] = 3.7
+        con_moon = prob.constraints(free)
+        np.savez(out, con=con, jac=jac, rows=rows, cols=cols,
+                 con_moon=con_moon,
+                 ab=np.array([prob.sharded.a, prob.sharded.b]))
+        prob.shutdown()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,backend', [(2, 'gloo'), (3, 'gloo'),
+                                           (1, 'nccl')])
+def test_sharded_problem_with_instance_constraints_vs_reference(
+        tmp_path, world, backend):
+    """BASELINE config 2 (N = 10 000, midpoint, FOUR instance constraints) as
+    an ``opty_amd.ShardedProblem`` -- ranks oversubscribed on one GPU under
+    gloo, and the RCCL code path with the one rank a 1-GPU box gives it --
+    against the reference's golden: sampled nodes, checksums over all nodes,
+    the instance tails of both vectors, int64 indices."""
+    import torch.multiprocessing as mp
+    import opty_amd
+    out = str(tmp_path/'root.npz')
+    mp.spawn(_config2_worker, args=(world, _free_port(), out, backend),
+             nprocs=world, join=True)
+    got = np.load(out)
+    meta, z = gu.load('config2_pendulum')
+    N, M, C = meta['N'], meta['M'], meta['C']
+    P = M*C
+    assert tuple(got['ab']) == (0, -(-(N - 1)//world))
+    con, jac = got['con'], got['jac']
+    assert len(con) == meta['num_constraints'] and len(jac) == meta['nnz']
+    col = opty_amd.ConstraintCollocator(**problems.build('config2_pendulum'))
+    free = problems.make_free(col.num_free, seed=meta['seed'])
+    nodes = z['nodes']
+    cbn, jbn, icb, ijb = gu.error_bounds(col, free, nodes)
+    blk = jac[:P*(N - 1)].reshape(N - 1, P)
+    cb = con[:M*(N - 1)].reshape(M, N - 1)
+    gu.assert_close(blk[nodes], z['jac_nodes'], RTOL,
+                    what='sharded config2 jac nodes', bound=jbn)
+    gu.assert_close(cb[:, nodes], z['con_nodes'], RTOL,
+                    what='sharded config2 con nodes', bound=cbn)
+    gu.assert_close(blk.sum(axis=0), z['jac_entry_sums'], 1e-9,
+                    scale=float(z['jac_abs_sum'][0])/P,
+                    what='sharded config2 jac entry sums')
+    gu.assert_close(cb.sum(axis=1), z['con_eq_sums'], 1e-9,
+                    scale=float(np.abs(cb).sum())/M,
+                    what='sharded config2 con sums')
+    gu.assert_close(con[M*(N - 1):], z['con_tail'], RTOL,
+                    what='sharded config2 con tail', bound=icb)
+    gu.assert_close(jac[P*(N - 1):], z['jac_tail'], RTOL,
+                    what='sharded config2 jac tail', bound=ijb)
+    rows, cols = got['rows'], got['cols']
+    assert rows.dtype == np.int64 and len(rows) == meta['nnz']
+    np.testing.assert_array_equal(
+        rows[:P*(N - 1)].reshape(N - 1, P)[nodes], z['rows_nodes'])
+    np.testing.assert_array_equal(
+        cols[:P*(N - 1)].reshape(N - 1, P)[nodes], z['cols_nodes'])
+    np.testing.assert_array_equal(rows[P*(N - 1):], z['rows_tail'])
+    np.testing.assert_array_equal(cols[P*(N - 1):], z['cols_tail'])
+    # known-parameter change on the root reached every rank: the single-GPU
+    # collocator with the same change
+    g = [k for k in col.known_parameter_map if str(k) == 'g'][0]
+    col.known_parameter_map[g] = 3.7
+    want = col.generate_constraint_function()(free)
+    assert not np.allclose(want, con)
+    np.testing.assert_allclose(got['con_moon'], want, rtol=1e-12, atol=1e-12)
 
 
 def _rccl_worker(rank, world, port, out):
