@@ -575,6 +575,8 @@ class _ModuleWriter(object):
             return max([K + 16 if wide else 0] +
                        [b - a for e0, e1 in grp
                         for a, b in self._chunks(e0, e1)])
+        if self._whole_block_strip(grp):
+            return width
         return min(K, width)
 
     def _group_body(self, grp, con_rows, slab_of):
@@ -637,10 +639,38 @@ class _ModuleWriter(object):
                 self._strip_lines(body, e0, e1, value, nv, R)
             elif self.csr():
                 self._strip_csr(body, e0, e1, value, nv)
+            elif self._whole_block_strip(grp):
+                self._strip_flat(body, value, nv)
             else:
                 self._strip_simple(body, e0, e1, value, nv)
         body.end_scope()
         return body.lines
+
+    def _whole_block_strip(self, grp):
+        """A wave that evaluates the WHOLE block of a small (P < 64)
+        node-major system: its 64 nodes' values are one contiguous span."""
+        strips = [rg for rg in grp if rg[1] > rg[0]]
+        return (not self.line_mode() and not self.csr() and
+                strips == [(0, self.p.P)] and self.p.P <= CSR_MAX_ROW)
+
+    def _strip_flat(self, body, value, nv):
+        """Small blocks (P < 64), node-major: the P values of the wave's 64
+        nodes are ONE contiguous span of 64*P doubles, ``jrow[nd*P + e]``.  The
+        whole P x 64 tile is staged and swept front to back by
+        ``opty_flush_flat`` -- every store instruction writes eight whole
+        128-byte lines -- instead of K-entry pieces at arbitrary 16-byte
+        offsets per node (``_strip_simple``: 256-byte segments, the pattern
+        that runs at half the line-aligned rate, profiles/r01_store_bench.txt)."""
+        P, K = self.p.P, self.o.chunk
+        for e in range(P):
+            if e % K == 0:
+                body.new_scope()
+            body.begin_entry()
+            body.lines.append('ring[%d + lane] = %s;' % (e*TS, value(e)))
+        body.lines.append('opty_wave_sync();')
+        body.lines.append('opty_flush_flat<%d>(ring, jrow, %s, lane);'
+                          % (P, nv))
+        body.lines.append('opty_wave_sync();')
 
     def _strip_lines(self, body, e0, e1, value, nv, R, width=None,
                      jrow='jrow', b0='b0'):

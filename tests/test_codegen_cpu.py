@@ -423,13 +423,15 @@ def test_csr_layout_program_order(name, prune):
         assert not full[:, sorted(set(range(P)) - set(sel))].any()
 
 
-@pytest.mark.parametrize('L', [1, 2, 3, 7, 16, 45, 64])
+@pytest.mark.parametrize('L', [1, 2, 3, 5, 7, 10, 12, 16, 24, 40, 45, 55, 63, 64])
 def test_flat_flush_model(L):
     """Python model of ``opty_flush_flat`` (opty_amd/csrc/opty_device.h):
     every element of the span is written exactly once, from the right
     (entry, node) of the tile, with 16-byte aligned pairs, for all sixteen
     positions of the span start within a 128-byte line and ragged node
-    counts."""
+    counts.  It sweeps the rows of the row-sorted layout and -- ``L = P`` --
+    the whole 64-node tile of a small (P < 64) node-major block
+    (``emit_hip._strip_flat``)."""
     steps = (64*L + 15 + 127)//128
     for phase in range(16):
         for nvalid in (64, 1, 37):
@@ -547,3 +549,24 @@ def test_merge_fixed_free_static_helper():
     np.testing.assert_allclose(
         merge([a, b], {a: lambda fr: 2.0*fr[:2]}, np.array([5.0, 6.0]),
               'traj', free), [[2.0, 2.0], [5.0, 6.0]])
+
+
+@pytest.mark.parametrize('name', ['elementary_be_small', 'chaplygin_be_small',
+                                  'one_eom_be_small', 'msd_mid_small'])
+def test_small_blocks_are_flushed_as_one_span(name):
+    """Node-major blocks with P < 64: one wave stages the whole P x 64 tile
+    and sweeps the contiguous 64*P-double span with ``opty_flush_flat<P>``
+    (whole 128-byte lines) instead of K-entry pieces per node."""
+    col = ConstraintCollocator(**problems.build(name))
+    prog = col._build_program()
+    assert prog.P < 64
+    source, meta = col.generate_source()
+    assert 'opty_flush16<' not in source and 'opty_flush8<' not in source
+    assert source.count('opty_flush_flat<%d>(ring, jrow, nvalid, lane)'
+                        % prog.P) == 2           # opty_jac and opty_conjac
+    # every entry is staged exactly once per kernel, in its own tile row
+    body = source[source.index('\nopty_jac('):]
+    body = body[:body.index('\n}\n')]
+    rows = [int(m) for m in re.findall(r'ring\[(\d+) \+ lane\] = ', body)]
+    assert rows == [e*65 for e in range(prog.P)]
+    assert meta['kernels']['jac']['lds_bytes'] >= 8*65*prog.P

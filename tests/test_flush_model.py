@@ -121,15 +121,18 @@ def test_every_element_written_once(name, chunk, groups, interleave):
     opts = EmitOptions(chunk=chunk, groups=groups, ablate='store_only',
                        interleave=interleave)
     source, meta = emit_module(prog, opts)
-    P = prog.P
+    _check_exactly_once(source, meta['groups'], prog.P, chunk)
+
+
+def _check_exactly_once(source, groups, P, chunk, phases=(0, 1, 6, 15),
+                        counts=(64, 1, 37)):
     R = chunk + 16
     parsed = parse_groups(source)
-    assert len(parsed) == len(meta['groups'])
-    for b0 in (0, 1, 6, 15):
-        for nvalid in (64, 1, 37):
+    assert len(parsed) == len(groups)
+    for b0 in phases:
+        for nvalid in counts:
             stores = {}
-            full_lines = 0
-            strips = [(rg, calls) for grp, pg in zip(meta['groups'], parsed)
+            strips = [(rg, calls) for grp, pg in zip(groups, parsed)
                       for rg, calls in zip(grp, pg)]
             assert sum(len(g) for g in parsed) == len(strips)
             for (e0, e1), calls in strips:
@@ -156,4 +159,34 @@ def test_every_element_written_once(name, chunk, groups, interleave):
             # all lines fully inside the block are written by 8 aligned
             # 16-byte pieces from ONE flush call -> whole-line stores
             nlines = (b0 + nvalid*P)//16 - (b0 + 15)//16
-            assert nlines > 0
+            assert nlines > 0 or nvalid*P < 31
+
+
+def test_exactly_once_over_block_widths():
+    """The same model over a seeded sweep of block widths the problem zoo
+    does not have: 28 widths P in [72, 377] (odd and even) x strip counts x
+    chunk widths x line phases x ragged node counts -- synthetic matrix
+    programs with P outputs, printed by the product's emitter."""
+    from opty_amd.codegen import ir
+    from opty_amd.codegen.program import matrix_program
+    from opty_amd.codegen.emit_hip import emit_matrix_module, _ModuleWriter
+    rng = np.random.default_rng(20250928)
+    widths = sorted(set(int(x) for x in rng.integers(72, 378, size=40)))[:28]
+    assert len(widths) == 28 and any(w % 2 for w in widths) and \
+        any(w % 2 == 0 for w in widths)
+    runs = 0
+    for P in widths:
+        dag = ir.DAG()
+        x = dag.input('cur', 0)
+        prog = matrix_program(dag, [x]*P, 1, 0, (1, P))
+        for chunk in (16, 32):
+            for groups in (None, 1, 2 + P % 3, 5):
+                opts = EmitOptions(chunk=chunk, groups=groups,
+                                   ablate='store_only')
+                source, _ = emit_matrix_module(prog, opts)
+                grp = _ModuleWriter(prog, opts).group_ranges()
+                _check_exactly_once(
+                    source, [[list(rg) for rg in g] for g in grp], P, chunk,
+                    phases=(0, 3, 8, 15), counts=(64, 1, 37))
+                runs += 1
+    assert runs == 28*2*4
