@@ -85,7 +85,11 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0, pad=0, occupancy=0, con_nt=None):
+                 interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=1):
+        # sin / cos through opty_sincos (opty_device.h: three-FMA reduction +
+        # minimax kernels, library fallback out of line) instead of the
+        # library's inline sincos; 0 for A/B runs
+        self.fast_trig = int(fast_trig)
         # non-temporal constraint stores: None = automatic (opty_con always;
         # opty_conjac when the constraint vector of a launch is too large to
         # stay in the caches, see emit_module), 0 / 1 = never / always
@@ -136,7 +140,8 @@ class EmitOptions(object):
                 (' pad=%d' % self.pad if self.pad else '') +
                 (' occupancy=%d' % self.occupancy if self.occupancy else '') +
                 (' con_nt=%d' % self.con_nt if self.con_nt is not None
-                 else ''))
+                 else '') +
+                ('' if self.fast_trig else ' fast_trig=0'))
 
 
 def _lit(v):
@@ -159,8 +164,9 @@ class _Body(object):
     scope (``new_scope``), computed temporaries are emitted once.
     """
 
-    def __init__(self, dag, needed, leaf):
+    def __init__(self, dag, needed, leaf, fast_trig=True):
         self.dag = dag
+        self.trig = 'opty_' if fast_trig else ''
         self.lines = []
         self.done = {}
         self.scope = {}
@@ -284,12 +290,13 @@ class _Body(object):
             if (j is not None and j in self.needed and not self._have(j)
                     and self.leaf(j) is None):
                 s_id, c_id = (i, j) if op == 'sin' else (j, i)
-                self.lines.append('double v%d, v%d; sincos(%s, &v%d, &v%d);'
-                                  % (s_id, c_id, r(a[0]), s_id, c_id))
+                self.lines.append('double v%d, v%d; %ssincos(%s, &v%d, &v%d);'
+                                  % (s_id, c_id, self.trig, r(a[0]), s_id,
+                                     c_id))
                 self.done[s_id] = 'v%d' % s_id
                 self.done[c_id] = 'v%d' % c_id
                 return
-            e = '%s(%s)' % (op, r(a[0]))
+            e = '%s%s(%s)' % (self.trig, op, r(a[0]))
         elif op == 'abs':
             e = 'fabs(%s)' % r(a[0])
         elif op == 'sign':
@@ -610,7 +617,7 @@ class _ModuleWriter(object):
                 return 'uni_c[%d]' % self._slot(i)
             return None
 
-        body = _Body(d, needed, leaf)
+        body = _Body(d, needed, leaf, self.o.fast_trig)
         for j in con_rows:
             body.new_scope()      # fetches hoisted per row, not per kernel
             ref = body.emit(p.con_out[j])
@@ -923,7 +930,8 @@ class _ModuleWriter(object):
                '    switch (blockIdx.x) {']
         for b in range(nparts):
             part = slots[b*len(slots)//nparts:(b + 1)*len(slots)//nparts]
-            body = _Body(d, set(d.reachable([i for i, _ in part])), leaf)
+            body = _Body(d, set(d.reachable([i for i, _ in part])), leaf,
+                         self.o.fast_trig)
             for i, s in part:
                 ref = body.emit(i)
                 body.lines.append('uni_w[%d] = %s;' % (s, ref))
@@ -947,7 +955,7 @@ class _ModuleWriter(object):
                 return self._scalar_source(i)
             return None
 
-        body = _Body(d, needed, leaf)
+        body = _Body(d, needed, leaf, self.o.fast_trig)
         for k, node in enumerate(p.inst_con_out):
             ref = body.emit(node)
             body.lines.append('if (con) con[%dLL*con_stride + %d] = %s;'
@@ -1030,6 +1038,84 @@ def _dual_occupancy_cut(prog, writer, opts, live_groups, con_waves,
     return dual, strips
 
 
+#: rough per-lane instruction weights of DAG operations (double precision on
+#: gfx950; opty_sincos is ~35 for the pair), for balancing work between waves
+_OP_WEIGHT = {'sin': 18, 'cos': 18, 'tan': 60, 'exp': 30, 'log': 35,
+              'sqrt': 12, ir.DIV: 12, ir.POW: 90, ir.ATAN2: 80, 'asin': 60,
+              'acos': 60, 'atan': 50, 'sinh': 60, 'cosh': 60, 'tanh': 60,
+              'erf': 60, 'erfc': 60, 'asinh': 70, 'acosh': 70, 'atanh': 70}
+
+
+def _node_weight(dag, i):
+    if dag.op[i] in (ir.CONST, ir.INPUT) or dag.uni[i]:
+        return 0
+    return _OP_WEIGHT.get(dag.op[i], 1)
+
+
+def _constraint_waves(prog, w, opts):
+    """Splits the M constraint rows over as few waves as the register budget
+    allows, balanced by WORK, not by count.
+
+    Every constraint wave re-reads the slab and recomputes the sub-expressions
+    its rows share with the others (all the sin / cos of a multibody system),
+    so one wave for all rows is fastest when it fits (10-link pendulum).  These
+    waves run one per SIMD whatever they need, so their budget is the whole
+    register file: 1.5 x ``max_live`` estimated temporaries is where spilling
+    starts (24-link, 50 rows: 10 / 5 / 4 / 2 waves of equal row COUNT have
+    estimates 123 / 174 / 227 / 532 and take 0.102 / 0.071 / 0.101 / 0.290 ms,
+    profiles/r02_strip_sweeps.txt).  Equal counts put the 25 trivial kinematic
+    rows ``q' - u`` of such a system into 2.5 waves and the 25 dynamic rows
+    into the other 2.5; instead the rows are cut into k contiguous ranges that
+    minimise the most expensive wave (operation weights, shared nodes counted
+    once per wave), for the smallest k whose ranges all fit the budget."""
+    dag, M = prog.dag, prog.M
+    if M <= 1:
+        return [list(range(M))]
+    leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
+    # cost[a][b]: work of one wave evaluating rows a..b-1
+    cost = [[0]*(M + 1) for _ in range(M)]
+    for a in range(M):
+        seen, total = set(), 0
+        for b in range(a, M):
+            stack = [prog.con_out[b]]
+            while stack:
+                i = stack.pop()
+                if i in seen:
+                    continue
+                seen.add(i)
+                if dag.op[i] in (ir.CONST, ir.INPUT) or dag.uni[i]:
+                    continue
+                total += _node_weight(dag, i)
+                stack.extend(dag.operands(i))
+            cost[a][b + 1] = total + 2*(b + 1 - a)       # + the row's store
+    budget = 1.5*opts.max_live
+    best = None
+    for k in range(1, M + 1):
+        # linear partition: minimise the largest range cost
+        INF = float('inf')
+        dp = [[INF]*(M + 1) for _ in range(k + 1)]
+        cut = [[0]*(M + 1) for _ in range(k + 1)]
+        dp[0][0] = 0
+        for parts in range(1, k + 1):
+            for b in range(parts, M + 1):
+                for a in range(parts - 1, b):
+                    c = max(dp[parts - 1][a], cost[a][b])
+                    if c < dp[parts][b]:
+                        dp[parts][b], cut[parts][b] = c, a
+        bounds, b = [M], M
+        for parts in range(k, 0, -1):
+            b = cut[parts][b]
+            bounds.append(b)
+        bounds.reverse()
+        sets = [list(range(bounds[t], bounds[t + 1])) for t in range(k)]
+        best = sets
+        worst = max(_max_live(dag, [[prog.con_out[j]] for j in rs], leaf)
+                    for rs in sets)
+        if worst <= budget:
+            break
+    return best
+
+
 def emit_matrix_module(prog, opts=None):
     """Module of a *matrix program* (``program.matrix_program``: a plain
     ``(rows x cols)`` matrix of expressions evaluated for ``n`` independent
@@ -1072,24 +1158,7 @@ def emit_module(prog, opts=None, node_blocks=None):
     if opts.con_rows_per_wave:
         con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
     else:
-        # As few constraint waves as the register budget allows: every wave
-        # re-reads the slab and recomputes the shared sub-expressions (the 24
-        # sincos of a 24-link system cost more than the rows themselves), so
-        # one wave for all rows is fastest when it fits (10-link pendulum).
-        # These waves run one per SIMD whatever they need, so their budget is
-        # the whole register file: 1.5 x max_live estimated temporaries is
-        # where spilling starts -- 24-link, 50 rows: 10/5/4/2 waves (estimates
-        # 123/174/227/532) take 0.102/0.071/0.101/0.290 ms
-        # (profiles/r02_strip_sweeps.txt).
-        leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
-        parts = 1
-        while True:
-            con_sets = row_sets(-(-prog.M//parts))
-            worst = max(_max_live(prog.dag, [[prog.con_out[j]] for j in rs],
-                                  leaf) for rs in con_sets)
-            if worst <= 1.5*opts.max_live or len(con_sets) >= prog.M:
-                break
-            parts += 1
+        con_sets = _constraint_waves(prog, w, opts)
     fused_jac = groups
     if opts.groups is None:
         live, auto = w.auto_groups()

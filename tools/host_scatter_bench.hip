@@ -64,6 +64,27 @@ scatter_flat(const double *__restrict__ src, double *__restrict__ dst,
     }
 }
 
+// 16-byte pieces where a run allows it: piece table (entry, width 1|2)
+__global__ void __launch_bounds__(256)
+scatter_pieces(const double *__restrict__ src, double *__restrict__ dst,
+               const int *__restrict__ piece_e, const int *__restrict__ piece_w,
+               int NP, long long P, long long nnodes, int npb) {
+    const long long n0 = (long long)blockIdx.x*npb;
+    for (int s = 0; s < npb; ++s) {
+        const long long i = n0 + s;
+        if (i >= nnodes) return;
+        for (int v = threadIdx.x; v < NP; v += 256) {
+            const int e = piece_e[v];
+            if (piece_w[v] == 2) {
+                const double2 x = *reinterpret_cast<const double2 *>(src + i*P + e);
+                *reinterpret_cast<double2 *>(dst + i*P + e) = x;
+            } else {
+                dst[i*P + e] = src[i*P + e];
+            }
+        }
+    }
+}
+
 __global__ void pack_kernel(const double *__restrict__ src,
                             double *__restrict__ packed,
                             const int *__restrict__ entries, int V,
@@ -76,6 +97,39 @@ __global__ void pack_kernel(const double *__restrict__ src,
         packed[g] = src[i*P + entries[v]];
     }
 }
+
+#include <atomic>
+#include <thread>
+struct Pool {
+    std::vector<std::thread> th;
+    std::atomic<int> ready{0}, done{0}, epoch{0}, quit{0};
+    const double *packed; double *dense; const int *run_s; const int *run_l;
+    int nruns, V, T, chunks; long long P, n;
+    void work(int t) {
+        int seen = 0;
+        while (true) {
+            while (epoch.load(std::memory_order_acquire) == seen) {
+                if (quit.load()) return;
+                __builtin_ia32_pause();
+            }
+            seen = epoch.load();
+            for (int c = 0; c < chunks; ++c) {
+                while (ready.load(std::memory_order_acquire) <= c) __builtin_ia32_pause();
+                long long a = n*c/chunks, b = n*(c + 1)/chunks;
+                long long i0 = a + (b - a)*t/T, i1 = a + (b - a)*(t + 1)/T;
+                for (long long i = i0; i < i1; ++i) {
+                    const double *sp = packed + i*V;
+                    double *d = dense + i*P;
+                    for (int r = 0; r < nruns; ++r) {
+                        memcpy(d + run_s[r], sp, run_l[r]*8);
+                        sp += run_l[r];
+                    }
+                }
+            }
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+};
 
 struct Job {
     const double *packed; double *dense; const int *entries;
@@ -179,8 +233,71 @@ int main(int argc, char **argv) {
             scatter_flat<<<grid, 256, 0, st>>>(d_dense, h_dense, d_ent, V, P, total); });
         check(label);
     }
+    {   // 16-byte pieces
+        std::vector<int> pe, pw;
+        for (int k = 0; k < V;) {
+            int k1 = k + 1;
+            while (k1 < V && ent[k1] == ent[k1 - 1] + 1) ++k1;
+            int e = ent[k], len = k1 - k;
+            if (e & 1) { pe.push_back(e); pw.push_back(1); ++e; --len; }
+            for (; len >= 2; len -= 2, e += 2) { pe.push_back(e); pw.push_back(2); }
+            if (len) { pe.push_back(e); pw.push_back(1); }
+            k = k1;
+        }
+        int *d_pe, *d_pw;
+        CHECK(hipMalloc(&d_pe, pe.size()*4)); CHECK(hipMalloc(&d_pw, pw.size()*4));
+        CHECK(hipMemcpy(d_pe, pe.data(), pe.size()*4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_pw, pw.data(), pw.size()*4, hipMemcpyHostToDevice));
+        char label[96];
+        snprintf(label, sizeof label, "kernel 16-byte pieces (%zu per node) -> mapped host", pe.size());
+        timeit(label, packed_b, [&] {
+            scatter_pieces<<<(unsigned)((n + 3)/4), 256, 0, st>>>(
+                d_dense, h_dense, d_pe, d_pw, (int)pe.size(), P, n, 4); });
+        check(label);
+    }
+    {   // (e) persistent pool, runs copied with memcpy, chunked D2H
+        std::vector<int> rs, rl;
+        for (int k = 0; k < V;) {
+            int k1 = k + 1;
+            while (k1 < V && ent[k1] == ent[k1 - 1] + 1) ++k1;
+            rs.push_back(ent[k]); rl.push_back(k1 - k); k = k1;
+        }
+        for (int T : {8, 16, 24, 32, 48}) {
+            for (int chunks : {8, 16, 32}) {
+                Pool pool;
+                pool.packed = h_packed; pool.dense = h_dense;
+                pool.run_s = rs.data(); pool.run_l = rl.data();
+                pool.nruns = (int)rs.size(); pool.V = V; pool.T = T;
+                pool.chunks = chunks; pool.P = P; pool.n = n;
+                for (int t = 0; t < T; ++t)
+                    pool.th.emplace_back([&pool, t] { pool.work(t); });
+                std::vector<hipEvent_t> ev(chunks);
+                for (auto &evt : ev) CHECK(hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+                char label[96];
+                snprintf(label, sizeof label, "pool: %d threads, %d chunks, SDMA packed + host scatter", T, chunks);
+                timeit(label, packed_b, [&] {
+                    pool.ready.store(0); pool.done.store(0);
+                    for (int c = 0; c < chunks; ++c) {
+                        long long a = n*c/chunks, b = n*(c + 1)/chunks;
+                        CHECK(hipMemcpyAsync(h_packed + a*V, d_packed + a*V, (size_t)(b - a)*V*8,
+                                             hipMemcpyDeviceToHost, st));
+                        CHECK(hipEventRecord(ev[c], st));
+                    }
+                    pool.epoch.fetch_add(1, std::memory_order_release);
+                    for (int c = 0; c < chunks; ++c) {
+                        CHECK(hipEventSynchronize(ev[c]));
+                        pool.ready.store(c + 1, std::memory_order_release);
+                    }
+                    while (pool.done.load(std::memory_order_acquire) < T) __builtin_ia32_pause();
+                });
+                check(label);
+                pool.quit.store(1);
+                for (auto &t : pool.th) t.join();
+            }
+        }
+    }
     // (d) packed D2H in chunks + CPU scatter threads
-    for (int threads : {4, 8, 16, 32, 64}) {
+    for (int threads : {16}) {
         for (int chunks : {1, 8}) {
             char label[96];
             snprintf(label, sizeof label, "packed D2H in %d chunk(s) + %d scatter threads", chunks, threads);
