@@ -157,6 +157,32 @@ int opty_hip_eval_jac(opty_hip_problem *p, const double *free, double *jac,
  * counterpart: IPOPT asks for them separately, :498-525, :552-562). */
 int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
                           double *jac, int32_t mem);
+/* ---- host-visible Jacobian: only what changed crosses PCIe ------------------
+ * The reference returns jacobian(free) in ONE persistent array that the next
+ * call overwrites (opty/direct_collocation.py:2814, :2885-2887) and whose
+ * per-node block is dense -- structural zeros and node-invariant entries
+ * included (:2589-2593).  opty_hip_set_varying_entries names the block entries
+ * whose value can differ between two evaluations with the same known
+ * parameters and node time interval (ascending, 0 <= e < P; everything else
+ * is a function of those alone: literal zeros, +-1, 1/h, masses ...).
+ * opty_hip_eval_jac_persistent(free, jac), both HOST, jac page-locked
+ * (opty_hip_host_alloc), then computes the same values as opty_hip_eval_jac
+ * but moves only the varying entries -- packed on the device, copied in chunks,
+ * scattered into `jac` by a pool of host threads -- whenever `jac` is the
+ * vector of the previous call and the invariant entries it holds are still
+ * valid (they are re-sent after opty_hip_set_known_parameters /
+ * opty_hip_set_interval).  The caller must not write into `jac` between
+ * calls.  Node-major layout only; without varying entries set it is
+ * opty_hip_eval_jac. */
+int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
+                                 int32_t count);
+int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
+                                 double *jac);
+/* Host threads of the scatter pool (per process; 0 = the default:
+ * OPTY_HIP_HOST_THREADS or min(16, hardware threads / 2)). */
+int opty_hip_set_host_threads(int32_t count);
+int opty_hip_host_threads(void);
+
 /* jacobian_indices(): writes nnz int64 rows and cols -- the closed form of
  * ConstraintCollocator.jacobian_indices (opty/direct_collocation.py:2450-2690,
  * formulas :2644-2675). */

@@ -230,3 +230,45 @@ def _column_key(n, q, method):
             return (n + k - 2*n - q)*big + 2
         return (n + q)*big + (k - 2*n - 2*q)
     return key
+
+
+def varying_entries(prog):
+    """Stored block entries whose value can differ between two evaluations
+    with the same known parameters and (fixed) node time interval: those that
+    depend on a trajectory value, an unknown parameter or a free interval.
+    The rest -- for the 10-link pendulum 660 of 990: the reference's
+    structural zeros, +-1, +-1/h, products of masses and lengths
+    (``opty/direct_collocation.py:2589-2593`` keeps them all in the value
+    vector) -- are the same at every node and every call."""
+    dag = prog.dag
+    static = {}
+
+    def is_static(root):
+        stack = [root]
+        while stack:
+            i = stack.pop()
+            if i in static:
+                if not static[i]:
+                    return False
+                continue
+            if dag.op[i] == ir.INPUT:
+                kind, idx = dag.args[i]
+                ok = ((kind == 'par' and prog.pars[idx][0] == 'known') or
+                      (kind == 'h' and prog.h[0] == 'fixed'))
+                static[i] = ok
+                if not ok:
+                    return False
+                continue
+            if not dag.uni[i]:
+                static[i] = False
+                return False
+            stack.extend(dag.operands(i))
+        return True
+
+    out = []
+    for e, node in enumerate(prog.jac_out):
+        ok = is_static(node)
+        static[node] = ok
+        if not ok:
+            out.append(e)
+    return out

@@ -11,11 +11,17 @@
 // _wrap_constraint_funcs (:2928-3001) and jacobian_indices (:2450-2690).
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/opty_hip.h"
@@ -139,6 +145,153 @@ opty_indices_kernel(IndexDims d, long long *rows, long long *cols,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Host-visible Jacobian: only what changed crosses PCIe.
+//
+// The reference hands IPOPT the DENSE per-node block (structural zeros and
+// node-invariant entries included, opty/direct_collocation.py:2589-2593) in a
+// persistent array (:2814).  For the 10-link pendulum 660 of the block's 990
+// entries are the same at every node and every call; moving all 792 MB over
+// PCIe Gen5 x16 takes 13.9 ms, the 264 MB that can change 4.6 ms.  The
+// varying entries of every node are packed on the device (opty_pack_kernel),
+// copied in chunks by the DMA engine into a page-locked staging vector, and
+// scattered into the caller's dense vector by a small pool of host threads
+// while the next chunk is in flight.  (Alternatives measured on MI355X,
+// profiles/r03_host_scatter.txt: a kernel storing the runs straight into
+// host-mapped memory 7.2-7.3 ms -- 64-byte PCIe writes, 36 GB/s; one
+// hipMemcpy2D per run 59 ms.)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+opty_pack_kernel(const double *__restrict__ jac, double *__restrict__ packed,
+                 const int *__restrict__ entries, int V, long long P,
+                 long long total) {
+    long long g = (long long)blockIdx.x*256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x*256;
+    for (; g < total; g += stride) {
+        const long long i = g/V;
+        const int v = (int)(g - i*V);
+        packed[g] = jac[i*P + entries[v]];
+    }
+}
+
+// Persistent pool of host threads (one per library and process) that scatter
+// packed node rows into a dense vector.  Between jobs the workers sleep on a
+// condition variable; during a job they poll the number of chunks that have
+// landed (a job lasts a few milliseconds).
+class ScatterPool {
+public:
+    struct Job {
+        const double *packed = nullptr;   // [node][V]
+        double *dense = nullptr;          // [node][P]
+        const int *run_start = nullptr, *run_len = nullptr;
+        int nruns = 0, V = 0, chunks = 0;
+        long long P = 0, nodes = 0;
+    };
+
+    static ScatterPool &instance() {
+        static ScatterPool *pool = nullptr;
+        static std::mutex guard;
+        std::lock_guard<std::mutex> lk(guard);
+        // a forked child inherits the object but none of its threads
+        if (!pool || pool->pid_ != getpid()) pool = new ScatterPool;
+        return *pool;
+    }
+
+    static int default_threads() {
+        if (const char *env = getenv("OPTY_HIP_HOST_THREADS")) {
+            const int n = atoi(env);
+            if (n > 0) return std::min(n, 256);
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(16u, hw/2));
+    }
+
+    int threads() const { return (int)workers_.size(); }
+
+    void resize(int n) {
+        stop();
+        n = std::max(1, std::min(n, 256));
+        quit_ = false;
+        for (int t = 0; t < n; ++t)
+            workers_.emplace_back([this, t, n] { work(t, n); });
+    }
+
+    // The caller publishes chunks [0, c) as landed with ready(c) and finally
+    // waits for the workers.
+    void start(const Job &job) {
+        job_ = job;
+        ready_.store(0, std::memory_order_relaxed);
+        done_.store(0, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            ++epoch_;
+        }
+        cv_.notify_all();
+    }
+    void ready(int chunks) { ready_.store(chunks, std::memory_order_release); }
+    void wait() {
+        while (done_.load(std::memory_order_acquire) < threads())
+            std::this_thread::yield();
+    }
+
+private:
+    ScatterPool() : pid_(getpid()) { resize(default_threads()); }
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+        workers_.clear();
+    }
+
+    void work(int t, int T) {
+        unsigned long long seen = 0;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            seen = epoch_;
+        }
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return quit_ || epoch_ != seen; });
+                if (quit_) return;
+                seen = epoch_;
+            }
+            const Job j = job_;
+            for (int c = 0; c < j.chunks; ++c) {
+                while (ready_.load(std::memory_order_acquire) <= c)
+                    __builtin_ia32_pause();
+                const long long a = j.nodes*c/j.chunks,
+                                b = j.nodes*(c + 1)/j.chunks;
+                const long long i0 = a + (b - a)*t/T,
+                                i1 = a + (b - a)*(t + 1)/T;
+                for (long long i = i0; i < i1; ++i) {
+                    const double *src = j.packed + i*j.V;
+                    double *dst = j.dense + i*j.P;
+                    for (int r = 0; r < j.nruns; ++r) {
+                        memcpy(dst + j.run_start[r], src,
+                               (size_t)j.run_len[r]*sizeof(double));
+                        src += j.run_len[r];
+                    }
+                }
+            }
+            done_.fetch_add(1, std::memory_order_release);
+        }
+    }
+
+    pid_t pid_;
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    unsigned long long epoch_ = 0;
+    bool quit_ = false;
+    Job job_;
+    std::atomic<int> ready_{0}, done_{0};
+};
+
 }  // namespace
 
 struct opty_hip_problem {
@@ -160,6 +313,13 @@ struct opty_hip_problem {
          have_h = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t last_stream = nullptr;   // stream of the last enqueued work
+    // host-visible Jacobian by varying entries (opty_hip_eval_jac_persistent)
+    std::vector<int> var_entries, run_start, run_len;
+    int *d_var = nullptr;
+    double *d_packed = nullptr, *h_packed = nullptr;
+    std::vector<hipEvent_t> chunk_events;
+    const double *static_host = nullptr;  // vector whose invariant entries
+    bool static_valid = false;            // ... are up to date
 
     int64_t ncon_nodes() const { return d.N - 1; }
     int64_t P() const { return (int64_t)d.P; }
@@ -801,11 +961,14 @@ int opty_hip_destroy(opty_hip_problem *p) {
     if (!p) return 0;
     (void)hipSetDevice(p->d.device);
     (void)hipStreamSynchronize(sync_target(p->stream));
-    void *bufs[] = {p->d_pattern, p->d_rowinfo, p->d_uni, p->d_params, p->d_known, p->d_inst_idx, p->d_inst_rows,
+    void *bufs[] = {p->d_pattern, p->d_rowinfo, p->d_uni, p->d_params,
+                    p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
-                    p->d_cols};
+                    p->d_cols, p->d_var, p->d_packed};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (p->h_packed) (void)hipHostFree(p->h_packed);
+    for (hipEvent_t e : p->chunk_events) (void)hipEventDestroy(e);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -840,6 +1003,7 @@ int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
                            hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     p->uni_dirty = true;
+    p->static_valid = false;    // node-invariant Jacobian entries change
     p->have_params = true;
     return 0;
 }
@@ -852,6 +1016,7 @@ int opty_hip_set_interval(opty_hip_problem *p, double h) {
     p->h = h;
     p->have_h = true;
     p->uni_dirty = true;
+    p->static_valid = false;
     return 0;
 }
 
@@ -1132,6 +1297,149 @@ int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
     return time_impl(p, what, free_, con, jac,
                      NodeRange{node_begin, node_end, con_stride}, false, iters,
                      ms_per_iter);
+}
+
+int opty_hip_set_host_threads(int32_t count) {
+    if (count < 0) return fail("thread count must be >= 0");
+    ScatterPool &pool = ScatterPool::instance();
+    pool.resize(count == 0 ? ScatterPool::default_threads() : count);
+    return 0;
+}
+
+int opty_hip_host_threads(void) { return ScatterPool::instance().threads(); }
+
+int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
+                                 int32_t count) {
+    if (!p) return fail("null handle");
+    if (p->d.layout != OPTY_HIP_LAYOUT_COO)
+        return fail("varying entries apply to the node-major layout only");
+    if (count < 0 || count > p->d.P) return fail("bad entry count %d", count);
+    if (count > 0 && !entries) return fail("null entries");
+    for (int v = 0; v < count; ++v)
+        if (entries[v] < 0 || entries[v] >= p->d.P ||
+            (v > 0 && entries[v] <= entries[v - 1]))
+            return fail("varying entries must ascend within [0, %d)", p->d.P);
+    if (int rc = use_device(p)) return rc;
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    p->var_entries.assign(entries, entries + count);
+    p->run_start.clear();
+    p->run_len.clear();
+    for (int v = 0; v < count; ++v) {
+        if (v > 0 && entries[v] == entries[v - 1] + 1) {
+            ++p->run_len.back();
+        } else {
+            p->run_start.push_back(entries[v]);
+            p->run_len.push_back(1);
+        }
+    }
+    if (p->d_var) (void)hipFree(p->d_var);
+    p->d_var = nullptr;
+    if (count > 0) {
+        HIP_TRY(hipMalloc((void **)&p->d_var, count*sizeof(int)));
+        HIP_TRY(hipMemcpy(p->d_var, entries, count*sizeof(int),
+                          hipMemcpyHostToDevice));
+    }
+    p->static_valid = false;
+    return 0;
+}
+
+int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
+                                 double *jac) {
+    if (!p) return fail("null handle");
+    if (!free_ || !jac) return fail("null buffer");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    const int V = (int)p->var_entries.size();
+    const long long P = p->P(), ncn = p->ncon_nodes();
+    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+    if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
+    if (int rc = order_streams(p)) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
+                           hipMemcpyHostToDevice, p->stream));
+    if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
+                             p->d_jac, whole(p), true))
+        return rc;
+    const bool full = !p->static_valid || p->static_host != jac ||
+                      p->d.layout != OPTY_HIP_LAYOUT_COO || p->d_var == nullptr
+                      || 2*V > P;     // nothing to gain: dense copy
+    if (full) {
+        HIP_TRY(hipMemcpyAsync(jac, p->d_jac, p->nnz()*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+        p->static_host = jac;
+        p->static_valid = p->d_var != nullptr || V == 0;
+        return 0;
+    }
+    if (V == 0) {       // a block of constants: only the instance tail moves
+        if (p->d.nnz_inst > 0)
+            HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
+                                   p->d.nnz_inst*sizeof(double),
+                                   hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+        return 0;
+    }
+    const size_t packed = (size_t)ncn*V;
+    if (int rc = ensure(&p->d_packed, packed)) return rc;
+    if (!p->h_packed)
+        HIP_TRY(hipHostMalloc((void **)&p->h_packed, packed*sizeof(double),
+                              hipHostMallocDefault));
+    // chunks of about 16 MB: long enough for the DMA engine's full rate,
+    // short enough that the host threads start early and finish soon after
+    // the last byte has landed
+    int chunks = (int)std::max<size_t>(1, std::min<size_t>(
+        32, packed*sizeof(double)/(16u << 20)));
+    chunks = (int)std::min<long long>(chunks, ncn);
+    while ((int)p->chunk_events.size() < chunks) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->chunk_events.push_back(e);
+    }
+    const unsigned grid = (unsigned)std::min<long long>(
+        ((long long)packed + 255)/256, 8192);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(opty_pack_kernel, dim3(grid), dim3(256), 0, p->stream,
+                       p->d_jac, p->d_packed, p->d_var, V, P,
+                       (long long)packed);
+    HIP_TRY(hipGetLastError());
+    for (int c = 0; c < chunks; ++c) {
+        const long long a = ncn*c/chunks, b = ncn*(c + 1)/chunks;
+        HIP_TRY(hipMemcpyAsync(p->h_packed + a*V, p->d_packed + a*V,
+                               (size_t)(b - a)*V*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
+    }
+    if (p->d.nnz_inst > 0)
+        HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
+                               p->d.nnz_inst*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    ScatterPool &pool = ScatterPool::instance();
+    ScatterPool::Job job;
+    job.packed = p->h_packed;
+    job.dense = jac;
+    job.run_start = p->run_start.data();
+    job.run_len = p->run_len.data();
+    job.nruns = (int)p->run_start.size();
+    job.V = V;
+    job.chunks = chunks;
+    job.P = P;
+    job.nodes = ncn;
+    pool.start(job);
+    int rc = 0;
+    for (int c = 0; c < chunks; ++c) {
+        hipError_t e = hipEventSynchronize(p->chunk_events[c]);
+        if (e != hipSuccess && rc == 0) {
+            (void)hipGetLastError();
+            rc = fail("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        }
+        pool.ready(c + 1);      // also after a failure: the workers must end
+    }
+    pool.wait();
+    if (rc) {
+        p->static_valid = false;
+        return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    return 0;
 }
 
 int opty_hip_host_register(void *ptr, size_t bytes) {

@@ -22,7 +22,7 @@ import sympy as sm
 import sympy.physics.mechanics as me
 
 from .utils import parse_free, sort_sympy
-from .codegen.program import build_program
+from .codegen.program import build_program, varying_entries
 from .codegen.emit_hip import emit_module, EmitOptions
 from . import hip_backend as hb
 
@@ -576,6 +576,8 @@ class ConstraintCollocator(object):
         self._sync_known(hip, None)
         if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
+        if self._jacobian_layout == 'coo':
+            hip.set_varying_entries(varying_entries(self._program))
         if self.num_instance_constraints:
             idx = self.instance_constraints_free_index_map
             hip.set_instance_indices([idx[f] for f in self._inst_atoms],
@@ -794,13 +796,29 @@ class ConstraintCollocator(object):
         hip = self._ensure_hip()
         # page-locked: the (up to GB-sized) copy back runs at PCIe rate
         result = hb.pinned_empty(hip.nnz)
+        # Large blocks: after the first call only the entries that can change
+        # cross PCIe (opty_hip_eval_jac_persistent; the node-invariant ones
+        # stay in `result`, which the caller must therefore treat as
+        # read-only -- cyipopt copies it).  OPTY_HOST_DENSE=1 moves the whole
+        # vector every call.
+        import os
+        persistent = (self._jacobian_layout == 'coo' and
+                      hip.nnz >= self._PERSISTENT_MIN_NNZ and
+                      os.environ.get('OPTY_HOST_DENSE') != '1')
 
         def jacobian(free):
             free = self._host_free(free)
             self._sync_known(hip, free)
-            hip.eval_jac(free, result, hb.HOST)
+            if persistent:
+                hip.eval_jac_persistent(free, result)
+            else:
+                hip.eval_jac(free, result, hb.HOST)
             return result
         return jacobian
+
+    #: Jacobian values below which the whole vector is copied every call (one
+    #: DMA of a few MB beats a pack kernel + chunks + host threads)
+    _PERSISTENT_MIN_NNZ = 1 << 20
 
     def jacobian_indices(self):
         """Row and column indices (int64) of every Jacobian value, in the

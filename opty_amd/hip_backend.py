@@ -194,6 +194,10 @@ _SIGNATURES = {
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64]),
     'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
+    'opty_hip_set_varying_entries': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
+    'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P]),
+    'opty_hip_set_host_threads': (ctypes.c_int, [ctypes.c_int32]),
+    'opty_hip_host_threads': (ctypes.c_int, []),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
@@ -299,6 +303,16 @@ def pinned_empty(count, dtype=np.float64):
 _PINNED_OWNERS = {}
 
 
+def set_host_threads(count=0):
+    """Host threads that scatter the varying Jacobian entries into the
+    caller's dense vector (0 = default)."""
+    _check(load_library().opty_hip_set_host_threads(int(count)))
+
+
+def host_threads():
+    return load_library().opty_hip_host_threads()
+
+
 def host_register(array):
     """Page-locks the memory of a NumPy array the caller owns (e.g. a
     shared-memory mapping); pair with :func:`host_unregister`."""
@@ -385,6 +399,19 @@ class HipProblem(object):
     def eval_jac(self, free, jac, mem):
         _check(self._lib.opty_hip_eval_jac(self._h, _ptr(free), _ptr(jac),
                                            mem))
+
+    def set_varying_entries(self, entries):
+        """Block entries that can change from call to call (ascending); see
+        ``opty_hip_set_varying_entries``."""
+        e = np.ascontiguousarray(entries, dtype=np.int32)
+        _check(self._lib.opty_hip_set_varying_entries(self._h, _ptr(e),
+                                                      len(e)))
+
+    def eval_jac_persistent(self, free, jac):
+        """``opty_hip_eval_jac_persistent``: host ``free``, page-locked
+        persistent host ``jac``."""
+        _check(self._lib.opty_hip_eval_jac_persistent(
+            self._h, _ptr(free), _ptr(jac)))
 
     def eval_con_jac(self, free, con, jac, mem):
         _check(self._lib.opty_hip_eval_con_jac(

@@ -570,3 +570,37 @@ def test_small_blocks_are_flushed_as_one_span(name):
     rows = [int(m) for m in re.findall(r'ring\[(\d+) \+ lane\] = ', body)]
     assert rows == [e*65 for e in range(prog.P)]
     assert meta['kernels']['jac']['lds_bytes'] >= 8*65*prog.P
+
+
+@pytest.mark.parametrize('name', ['config3_10link_small',
+                                  'pend2_link_vardur_unkmass_small',
+                                  'gaitlike_3link_be_small',
+                                  'chaplygin_be_small', 'msd_be_small'])
+def test_varying_entries_against_the_reference_values(name):
+    """``program.varying_entries``: every block entry NOT in the list has one
+    value at all nodes of the reference's golden Jacobian (and, for problems
+    without unknown parameters / free interval, that value does not depend on
+    ``free``: the oracle is not needed, the static entries' DAG nodes have no
+    trajectory or free-tail input)."""
+    from opty_amd.codegen.program import varying_entries
+    meta, z = gu.load(name)
+    col = ConstraintCollocator(**problems.build(name))
+    prog = col._build_program()
+    var = varying_entries(prog)
+    assert var == sorted(set(var)) and all(0 <= e < prog.P for e in var)
+    P, ncn = prog.P, meta['N'] - 1
+    blk = z['jac'][:P*ncn].reshape(ncn, P)
+    static = sorted(set(range(P)) - set(var))
+    assert (blk[:, static] == blk[0, static]).all()
+    # the list is not vacuous: most listed entries do change between nodes
+    moving = (blk[:, var] != blk[0, var]).any(axis=0)
+    assert moving.sum() >= 0.6*len(var)
+    if meta['r'] or meta['s']:
+        # entries that read the free tail count as varying
+        dag = prog.dag
+        tail = {i for i in range(len(dag)) if dag.op[i] == ir.INPUT and (
+            (dag.args[i][0] == 'par' and
+             prog.pars[dag.args[i][1]][0] == 'tail') or
+            (dag.args[i][0] == 'h' and prog.h[0] != 'fixed'))}
+        for e in static:
+            assert not tail & set(dag.reachable([prog.jac_out[e]]))

@@ -738,3 +738,46 @@ def test_small_launch_geometry_matches_default(overrides, N, explicit):
     small.hip.eval_con_jac(free, c2, j2, hb.HOST)
     gu.assert_close(c2, c0, 1e-12, what='small-launch fused con', bound=cb)
     gu.assert_close(j2, j0, 1e-12, what='small-launch fused jac', bound=jb)
+
+
+@pytest.mark.parametrize('name,N', [('config3_10link', 20001),
+                                    ('config2_pendulum', 100001),
+                                    ('pend2_link_vardur_unkmass_small', 9001)])
+def test_persistent_jacobian_moves_only_what_changed(name, N):
+    """``jacobian(free)`` through ``opty_hip_eval_jac_persistent`` (varying
+    entries packed, copied in chunks, scattered by the host thread pool) is
+    bit for bit the dense copy of ``opty_hip_eval_jac`` -- first call, later
+    calls with other vectors, after a known-parameter change, with one, three
+    and the default number of host threads, instance tail included."""
+    from opty_amd import hip_backend as hb
+    col = _collocator(name, num_nodes=N)
+    hip = col.hip
+    assert hip.nnz >= col._PERSISTENT_MIN_NNZ
+    jac = col.generate_jacobian_function()
+    vd = col._variable_duration
+    frees = [problems.make_free(col.num_free, seed=s, variable_duration=vd)
+             for s in (1, 2, 3, 4)]
+    dense = hb.pinned_empty(hip.nnz)
+
+    def check(free):
+        got = jac(free)
+        hip.eval_jac(free, dense, hb.HOST)
+        np.testing.assert_array_equal(got, dense)
+    try:
+        check(frees[0])                     # first call: whole vector
+        check(frees[1])                     # varying entries only
+        hb.set_host_threads(1)
+        check(frees[2])
+        hb.set_host_threads(3)
+        check(frees[3])
+        if col.num_known_parameters:
+            key = list(col.known_parameter_map)[-1]
+            old = col.known_parameter_map[key]
+            col.known_parameter_map[key] = 1.5*float(old) + 0.25
+            check(frees[0])                 # invariant entries re-sent
+            check(frees[1])
+            col.known_parameter_map[key] = old
+            check(frees[2])
+    finally:
+        hb.set_host_threads(0)
+    assert hb.host_threads() >= 1
