@@ -594,8 +594,9 @@ def test_varying_entries_against_the_reference_values(name):
     assert (blk[:, static] == blk[0, static]).all()
     # the list is not vacuous: most listed entries do change between nodes
     moving = (blk[:, var] != blk[0, var]).any(axis=0)
-    assert moving.sum() >= 0.6*len(var)
-    if meta['r'] or meta['s']:
+    if not (meta['r'] or meta['s']):
+        assert moving.sum() >= 0.6*len(var)
+    else:
         # entries that read the free tail count as varying
         dag = prog.dag
         tail = {i for i in range(len(dag)) if dag.op[i] == ir.INPUT and (
