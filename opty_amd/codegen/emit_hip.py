@@ -85,10 +85,14 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=1):
-        # sin / cos through opty_sincos (opty_device.h: three-FMA reduction +
-        # minimax kernels, library fallback out of line) instead of the
-        # library's inline sincos; 0 for A/B runs
+                 interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0):
+        # 1: sin / cos through opty_sincos (opty_device.h: three-FMA reduction
+        # + minimax kernels, library path in a cold branch) instead of the
+        # library's inline sincos.  Measured on MI355X (profiles/
+        # r03_ab_fast_trig.txt): no gain -- 10-link fused 0.1362 vs 0.1357 ms,
+        # 24-link 0.3848 vs 0.3841 ms, node shards the same -- the kernels
+        # wait on LDS / scalar loads / the store queue, not on the vector
+        # ALU; kept as an option, off by default
         self.fast_trig = int(fast_trig)
         # non-temporal constraint stores: None = automatic (opty_con always;
         # opty_conjac when the constraint vector of a launch is too large to
@@ -141,7 +145,7 @@ class EmitOptions(object):
                 (' occupancy=%d' % self.occupancy if self.occupancy else '') +
                 (' con_nt=%d' % self.con_nt if self.con_nt is not None
                  else '') +
-                ('' if self.fast_trig else ' fast_trig=0'))
+                (' fast_trig=1' if self.fast_trig else ''))
 
 
 def _lit(v):

@@ -122,7 +122,7 @@ class _MatrixFunction(object):
 
 
 def ufuncify_matrix(args, expr, const=None, tmp_dir=None, parallel=False,
-                    show_compile_output=False, device=0):
+                    show_compile_output=False, device=0, emit_options=None):
     """Returns ``f(result, *num_args) -> result.reshape(n, rows, cols)`` that
     evaluates a matrix of expressions for ``n`` argument rows on the GPU: the
     reference's plugin entry point with the reference's call contract
@@ -137,7 +137,8 @@ def ufuncify_matrix(args, expr, const=None, tmp_dir=None, parallel=False,
     arguments: evaluated in place on the handle's stream).
 
     ``tmp_dir`` is the code-object cache directory, ``parallel`` is accepted
-    and ignored (a launch is always parallel).  A build failure raises
+    and ignored (a launch is always parallel); ``device`` (HIP ordinal) and
+    ``emit_options`` (printer knobs) are extras.  A build failure raises
     ``ImportError`` with the compiler's stderr (``:912-916``).  Symbol
     *names* never reach the generated code (expressions are lowered to an
     operation DAG), so names that break the reference's C --
@@ -173,4 +174,4 @@ def ufuncify_matrix(args, expr, const=None, tmp_dir=None, parallel=False,
     outputs = [low.lower(e) for e in matrix]    # row-major
     return _MatrixFunction(dag, outputs, nvec, const_positions, len(args),
                            matrix.shape, tmp_dir, show_compile_output,
-                           device)
+                           device, emit_options)

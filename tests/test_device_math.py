@@ -108,11 +108,14 @@ def test_device_sincos_against_numpy():
     fast path, slow (library) path beyond 2^20, NaN, Inf."""
     import sympy as sm
     import opty_amd
+    from opty_amd.codegen.emit_hip import EmitOptions
     a = sm.symbols('a')
+    opts = dict(emit_options=EmitOptions(fast_trig=1))
     f = opty_amd.ufuncify_matrix((a,), sm.Matrix([[sm.sin(a), sm.cos(a)],
-                                                  [sm.sin(a), 2*sm.cos(a)]]))
-    f_sin = opty_amd.ufuncify_matrix((a,), sm.Matrix([[sm.sin(a)]]))
-    f_cos = opty_amd.ufuncify_matrix((a,), sm.Matrix([[sm.cos(a)]]))
+                                                  [sm.sin(a), 2*sm.cos(a)]]),
+                                 **opts)
+    f_sin = opty_amd.ufuncify_matrix((a,), sm.Matrix([[sm.sin(a)]]), **opts)
+    f_cos = opty_amd.ufuncify_matrix((a,), sm.Matrix([[sm.cos(a)]]), **opts)
     assert 'opty_sincos(' in f.source and 'opty_sin(' in f_sin.source \
         and 'opty_cos(' in f_cos.source
     rng = np.random.default_rng(11)
