@@ -85,7 +85,19 @@ class EmitOptions(object):
 
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
-                 interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0):
+                 interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
+                 fused_groups=None, small_flush='flat'):
+        # strips of opty_conjac when they differ from opty_jac's ``groups``
+        # (None: as ``groups``, or automatic); what a measured launch plan
+        # sets (opty_amd/launch_plan.py)
+        self.fused_groups = None if fused_groups is None \
+            else int(fused_groups)
+        # node-major blocks with P < 64: 'flat' stages the whole P x 64 tile
+        # and sweeps it as one span (opty_flush_flat), 'chunk' flushes K-entry
+        # pieces per node (smaller tile: more waves per CU, which a block of
+        # expensive expressions prefers)
+        assert small_flush in ('flat', 'chunk')
+        self.small_flush = small_flush
         # 1: sin / cos through opty_sincos (opty_device.h: three-FMA reduction
         # + minimax kernels, library path in a cold branch) instead of the
         # library's inline sincos.  Measured on MI355X (profiles/
@@ -145,7 +157,10 @@ class EmitOptions(object):
                 (' occupancy=%d' % self.occupancy if self.occupancy else '') +
                 (' con_nt=%d' % self.con_nt if self.con_nt is not None
                  else '') +
-                (' fast_trig=1' if self.fast_trig else ''))
+                (' fast_trig=1' if self.fast_trig else '') +
+                (' fused_groups=%d' % self.fused_groups
+                 if self.fused_groups is not None else '') +
+                ('' if self.small_flush == 'flat' else ' small_flush=chunk'))
 
 
 def _lit(v):
@@ -662,6 +677,7 @@ class _ModuleWriter(object):
         node-major system: its 64 nodes' values are one contiguous span."""
         strips = [rg for rg in grp if rg[1] > rg[0]]
         return (not self.line_mode() and not self.csr() and
+                self.o.small_flush == 'flat' and
                 strips == [(0, self.p.P)] and self.p.P <= CSR_MAX_ROW)
 
     def _strip_flat(self, body, value, nv):
@@ -1185,10 +1201,19 @@ def emit_module(prog, opts=None, node_blocks=None):
                 groups = w.group_ranges(fit)
             fused = _fit_one_round(fused, len(con_sets), int(node_blocks),
                                    live)
+        if opts.fused_groups is not None:
+            fused = opts.fused_groups
         if fused != len(groups):
             fused_jac = w.group_ranges(fused)
         else:
             fused_jac = groups
+    elif opts.fused_groups is not None:
+        fused_jac = w.group_ranges(opts.fused_groups)
+    seeds = dict(jac=len(groups), fused=len(fused_jac),
+                 con_waves=len(con_sets), chunk=opts.chunk,
+                 waves=opts.waves, occupancy=opts.occupancy,
+                 line_mode=bool(w.line_mode()),
+                 live=w.auto_groups()[0] if opts.groups is None else None)
     con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
@@ -1232,7 +1257,7 @@ def emit_module(prog, opts=None, node_blocks=None):
                 groups=[[list(rg) for rg in grp] for grp in groups],
                 fused_groups=[[list(rg) for rg in grp] for grp in fused_jac],
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
-                layout=getattr(prog, 'layout', 'coo'),
+                geometry=seeds, layout=getattr(prog, 'layout', 'coo'),
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
                 sha=hashlib.sha256(source.encode()).hexdigest())
     return source, meta

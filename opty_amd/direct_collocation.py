@@ -114,7 +114,10 @@ class ConstraintCollocator(object):
         self._show_compile_output = show_compile_output
         self._backend = backend
         self._device = int(device)
-        self._emit_options = emit_options or EmitOptions()
+        # printer options: the caller's, else (generate_source) the measured
+        # launch plan of this problem and launch size, else the printer's own
+        # rules
+        self._emit_options = emit_options
 
         self._sort_parameters()
         self._sort_trajectories()
@@ -524,8 +527,26 @@ class ConstraintCollocator(object):
     def generate_source(self):
         """HIP source of this problem's kernels and its launch metadata."""
         nodes = self._launch_nodes or self.num_collocation_nodes - 1
-        return emit_module(self._build_program(), self._emit_options,
-                           node_blocks=(int(nodes) + 63)//64)
+        blocks = (int(nodes) + 63)//64
+        prog = self._build_program()
+        opts = self._emit_options
+        if opts is None:
+            from . import launch_plan
+            opts = launch_plan.lookup(prog, blocks) or EmitOptions()
+        return emit_module(prog, opts, node_blocks=blocks)
+
+    def tune_launch(self, **kwargs):
+        """Times the neighbouring launch geometries of this problem on the
+        device, records the winners in the launch-plan file
+        (:mod:`opty_amd.launch_plan`) and rebuilds this collocator's kernels
+        with them.  Returns the plan entry."""
+        from . import launch_plan
+        entry = launch_plan.tune(self, **kwargs)
+        if self._hip is not None:
+            self._hip.close()
+        self._hip = None
+        self._emit_options = None
+        return entry
 
     def _descriptor(self, meta):
         prog = self._program
@@ -568,12 +589,24 @@ class ConstraintCollocator(object):
         hsaco = hb.compile_module(source, self.tmp_dir,
                                   self.show_compile_output)
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
+        self._install_tables(hip)
+        self._kernel_meta = meta
+        self._hip = hip
+        return hip
+
+    def _install_tables(self, hip):
+        """Uploads the node-invariant data of this problem into a handle."""
         if not self._variable_duration:
             hip.set_interval(self.node_time_interval)
         self._callable_known = any(
             callable(v) for v in self.known_trajectory_map.values())
         self._uploaded_parameters = self._uploaded_trajectories = None
         self._sync_known(hip, None)
+        if self._callable_known and self.num_known_input_trajectories:
+            # placeholders until the first evaluation supplies `free`
+            hip.set_known_trajectories(self._known_trajectory_array(
+                np.ones(self.num_free)))
+            self._uploaded_trajectories = None
         if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
         if self._jacobian_layout == 'coo':
@@ -582,9 +615,6 @@ class ConstraintCollocator(object):
             idx = self.instance_constraints_free_index_map
             hip.set_instance_indices([idx[f] for f in self._inst_atoms],
                                      self._inst_rows, self._inst_cols)
-        self._kernel_meta = meta
-        self._hip = hip
-        return hip
 
     @property
     def hip(self):

@@ -1,0 +1,236 @@
+"""Measured launch plans: the strip counts of a problem's kernels chosen by
+timing them on the device instead of by the printer's rules of thumb.
+
+The printer (``codegen/emit_hip.py``) picks the number of waves that share a
+64-node block from register estimates and two constants fitted to one family
+of systems (``STRIP_ENTRIES``, ``FUSED_STRIPS_PER_SQRT_ENTRY``: n-link
+pendulums on the boxes round 2 happened to lease).  Those stay as SEEDS.
+:func:`tune` builds the neighbouring geometries of a problem (in parallel:
+``hipcc`` is a subprocess), times them interleaved on the GPU through
+``opty_hip_time_eval_shard`` at the launch size the handle will be used at, and
+records the winners; :func:`lookup` is consulted by
+``ConstraintCollocator`` whenever the caller did not pass printer options.
+
+Plan file (JSON, ``opty_amd/launch_plans.json``, tracked; ``OPTY_LAUNCH_PLANS``
+overrides the path, ``OPTY_LAUNCH_PLANS=off`` disables lookups)::
+
+    {"<problem sha>:<launch bucket>:<arch>": {
+        "options": {"groups": 10, "fused_groups": 9, ...},   # EmitOptions kwargs
+        "seed": {"jac": 10, "fused": 9},                      # what the rules said
+        "measured_ms": {"fused": {"8": 0.1374, "9": 0.1359, ...},
+                        "jac": {...}},
+        "nodes": 99999, "device": "AMD Instinct MI355X", "problem": "..."}}
+
+* problem sha: sha-256 of the module the printer emits with its default
+  options for "large launches" -- it changes with the equations, the
+  discretisation and the printer itself, so a stale plan is never applied;
+* launch bucket: ``round(log2(64-node blocks of one launch))``, capped at 12
+  (launches of 4096 blocks and more fill the chip many times over and share
+  one optimum; a 196-block node shard does not);
+* arch: the code-object target (``gfx950``).
+"""
+
+import json
+import math
+import os
+
+from . import hip_backend as hb
+from .codegen.emit_hip import EmitOptions, emit_module
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_FILE = os.path.join(_PKG, 'launch_plans.json')
+_cache = {}
+
+
+def plan_path():
+    path = os.environ.get('OPTY_LAUNCH_PLANS', DEFAULT_FILE)
+    return None if path == 'off' else path
+
+
+def _load(path):
+    if path is None:
+        return {}
+    try:
+        mtime = os.path.getmtime(path)
+    except OSError:
+        return {}
+    hit = _cache.get(path)
+    if hit is None or hit[0] != mtime:
+        try:
+            with open(path) as f:
+                _cache[path] = (mtime, json.load(f))
+        except (OSError, ValueError):
+            _cache[path] = (mtime, {})
+    return _cache[path][1]
+
+
+def bucket(node_blocks):
+    """Launch-size class of a launch of ``node_blocks`` 64-node blocks."""
+    return min(12, int(round(math.log2(max(1, int(node_blocks))))))
+
+
+def problem_sha(prog):
+    """Identity of a collocation program for the plan file."""
+    _, meta = emit_module(prog, EmitOptions(), node_blocks=None)
+    return meta['sha'][:20]
+
+
+def key_of(prog, node_blocks, sha=None):
+    return '%s:%d:%s' % (sha or problem_sha(prog), bucket(node_blocks),
+                         hb.ARCH)
+
+
+def lookup(prog, node_blocks):
+    """``EmitOptions`` of the measured plan for this program and launch size,
+    or None."""
+    plans = _load(plan_path())
+    if not plans:
+        return None
+    entry = plans.get(key_of(prog, node_blocks))
+    if not entry:
+        return None
+    try:
+        return EmitOptions(**entry['options'])
+    except (TypeError, AssertionError, KeyError):
+        return None                     # written by another printer version
+
+
+def record(key, entry, path=None):
+    """Merges one entry into the plan file (atomic replace)."""
+    path = path or plan_path() or DEFAULT_FILE
+    plans = dict(_load(path))
+    plans[key] = entry
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    with open(tmp, 'w') as f:
+        json.dump(plans, f, indent=1, sort_keys=True)
+    os.replace(tmp, path)
+    _cache.pop(path, None)
+
+
+def _neighbours(seed, low, high):
+    out = {seed, seed - 1, seed + 1, seed + 2}
+    out |= {int(round(seed*f)) for f in (0.75, 0.88, 1.12, 1.25, 1.5)}
+    return sorted(g for g in out if low <= g <= high)
+
+
+def candidates(prog, node_blocks):
+    """Printer-option variants worth timing around the seed geometry:
+    ``[(label, options kwargs)]``, the seed first."""
+    _, meta = emit_module(prog, EmitOptions(), node_blocks=node_blocks)
+    g = meta['geometry']
+    seed = dict(groups=g['jac'], fused_groups=g['fused'])
+    if g['chunk'] != 32 or g['occupancy']:
+        # the small-launch geometry (two waves per SIMD) came with its own
+        # chunk / workgroup width: keep them with the seed
+        seed.update(chunk=g['chunk'], waves=g['waves'],
+                    occupancy=g['occupancy'])
+    out = [('seed', dict(seed))]
+    if not g['line_mode']:
+        if prog.P <= 64:
+            out.append(('chunk', dict(small_flush='chunk')))
+        return out, g
+    unit = 16
+    top = max(1, min(32, prog.P//unit))
+    low = max(1, -(-3*(g['live'] or 1)//5))
+    for f in _neighbours(g['fused'], low, top):
+        if f != g['fused']:
+            out.append(('fused=%d' % f, dict(seed, fused_groups=f)))
+    for j in _neighbours(g['jac'], low, top):
+        if j != g['jac']:
+            out.append(('jac=%d' % j, dict(seed, groups=j)))
+    return out, g
+
+
+def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
+         max_workers=6):
+    """Times the candidate geometries of ``collocator``'s problem at its
+    launch size on its device and records the winners.  Needs ``torch`` (for
+    the device buffers) and a GPU.  Returns the plan entry."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    col = collocator
+    prog = col._build_program()
+    nodes = int(col._launch_nodes or col.num_collocation_nodes - 1)
+    blocks = (nodes + 63)//64
+    cands, geo = candidates(prog, blocks)
+    dev = torch.device('cuda', col._device)
+    built = []
+
+    def build(item):
+        label, kw = item
+        source, meta = emit_module(prog, EmitOptions(**kw),
+                                   node_blocks=blocks)
+        return label, kw, meta, hb.compile_module(source, col.tmp_dir)
+
+    with ThreadPoolExecutor(max_workers) as pool:
+        built = list(pool.map(build, cands))
+    f64 = dict(dtype=torch.float64, device=dev)
+    N = col.num_collocation_nodes
+    rng = np.random.default_rng(1)
+    free = rng.uniform(-1.0, 1.0, col.num_free)
+    if col._variable_duration:
+        free[-1] = 0.01
+    free = torch.from_numpy(free).to(dev)
+    a = max(0, (N - 1 - nodes)//2)
+    b = a + nodes
+    con = torch.empty((prog.M, nodes), **f64)
+    jac = torch.empty(nodes*prog.P, **f64)
+    handles = []
+    for label, kw, meta, hsaco in built:
+        h = hb.HipProblem(col._descriptor(meta), hsaco)
+        col._install_tables(h)
+        h.use_torch_stream()
+        handles.append(h)
+    times = {k: [[] for _ in built] for k in ('fused', 'jac')}
+    sel = {'fused': hb.EVAL_FUSED, 'jac': hb.EVAL_JAC}
+    # clock ramp
+    for _ in range(3):
+        handles[0].time_eval_shard(hb.EVAL_FUSED, free, con, nodes, jac, a, b,
+                                   iters)
+    for _ in range(rounds):
+        for k, h in enumerate(handles):
+            for what in ('fused', 'jac'):
+                label = built[k][0]
+                if what == 'fused' and label.startswith('jac='):
+                    continue
+                if what == 'jac' and label.startswith('fused='):
+                    continue
+                times[what][k].append(h.time_eval_shard(
+                    sel[what], free, con, nodes, jac, a, b, iters))
+    for h in handles:
+        h.close()
+    best = {}
+    measured = {'fused': {}, 'jac': {}}
+    for what in ('fused', 'jac'):
+        for k, (label, kw, meta, _) in enumerate(built):
+            if not times[what][k]:
+                continue
+            ms = float(np.median(times[what][k]))
+            tag = label if label in ('seed', 'chunk') else label.split('=')[1]
+            if label == 'seed':
+                tag = str(geo['fused'] if what == 'fused' else geo['jac'])
+            measured[what][tag] = ms
+            # a challenger must beat the seed by more than run-to-run noise
+            margin = 0.0 if label == 'seed' else 0.01
+            if what not in best or ms < best[what][0]*(1.0 - margin):
+                best[what] = (ms, label, kw)
+            if log:
+                log('%-10s %-6s %.4f ms' % (label, what, ms))
+    if geo['line_mode']:
+        options = dict(built[0][1])
+        options['fused_groups'] = best['fused'][2]['fused_groups']
+        options['groups'] = best['jac'][2]['groups']
+    else:
+        # small blocks: the only choice is how the tile is flushed; the fused
+        # kernel (what a solver's pair costs) decides
+        options = dict(small_flush='chunk') \
+            if best['fused'][1] == 'chunk' else {}
+    sha = problem_sha(prog)
+    entry = dict(options=options,
+                 seed=dict(jac=geo['jac'], fused=geo['fused']),
+                 measured_ms=measured, nodes=nodes,
+                 device=torch.cuda.get_device_name(dev), problem_sha=sha)
+    if save:
+        record(key_of(prog, blocks, sha), entry, path)
+    return entry
