@@ -371,7 +371,8 @@ hipStream_t sync_target(hipStream_t s) {
     return s == (hipStream_t)OPTY_HIP_STREAM_LEGACY ? nullptr : s;
 }
 
-int order_streams(opty_hip_problem *p) {
+template <typename Handle>
+int order_streams(Handle *p) {
     if (p->last_stream && p->last_stream != p->stream) {
         // A switch is rare (set-up code, tests): wait for the old stream on
         // the host.  (An event recorded on hipStreamLegacy and waited for
@@ -554,6 +555,7 @@ struct opty_hip_objective {
     hipModule_t module = nullptr;
     hipFunction_t k_grad = nullptr, k_fin = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the last enqueued work
     double *d_partial = nullptr, *d_value = nullptr;
     double *d_free = nullptr, *d_grad = nullptr;   // staging for host callers
     long long nblk = 0;
@@ -633,6 +635,9 @@ int opty_hip_objective_eval(opty_hip_objective *o, const double *free_,
                             double *value, double *grad, int32_t mem) {
     if (!o || !free_ || !value) return fail("null argument");
     HIP_TRY(hipSetDevice(o->d.device));
+    // d_partial / d_value (and the staging buffers) may still be in use on
+    // the stream the handle was on before opty_hip_objective_set_stream
+    if (int rc = order_streams(o)) return rc;
     const double *dfree = free_;
     double *dgrad = grad;
     if (mem == OPTY_HIP_HOST) {
@@ -684,6 +689,7 @@ struct opty_hip_matrix {
     hipModule_t module = nullptr;
     hipFunction_t k_mat = nullptr, k_uni = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t last_stream = nullptr;   // stream of the last enqueued work
     double *d_args = nullptr, *d_result = nullptr, *d_const = nullptr,
            *d_uni = nullptr;
     size_t args_cap = 0, result_cap = 0;    // doubles
@@ -796,6 +802,10 @@ int opty_hip_matrix_eval(opty_hip_matrix *m, double *result,
     for (int k = 0; k < m->d.num_vec; ++k)
         if (!vec_args[k]) return fail("vector argument %d is null", k);
     HIP_TRY(hipSetDevice(m->d.device));
+    // the packed arguments, the const table and the node-invariant table may
+    // still be in use on the stream the handle was on before
+    // opty_hip_matrix_set_stream
+    if (int rc = order_streams(m)) return rc;
     const size_t size = (size_t)m->d.rows*m->d.cols;
     // the kernel reads the vector arguments as the rows of ONE (num_vec, n)
     // array (what `free` is to the collocation kernels): pack them

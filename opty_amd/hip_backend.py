@@ -111,9 +111,10 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     if os.path.exists(hsaco):
         logger.info('code object cache hit: %s', hsaco)
         return hsaco
-    # several ranks may build the same module at once: private temp names,
-    # atomic renames
-    tag = '.%d.tmp' % os.getpid()
+    # several ranks (or threads) may build the same module at once: private
+    # temp names, atomic renames
+    import threading
+    tag = '.%d.%d.tmp' % (os.getpid(), threading.get_ident())
     src_tmp = base + tag + '.hip'
     with open(src_tmp, 'w') as f:
         f.write(source)

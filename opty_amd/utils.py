@@ -57,6 +57,7 @@ class _MatrixFunction(object):
         from . import hip_backend as hb
         self.shape = shape
         self.num_args = num_args
+        self._on_torch_stream = False
         self.const_positions = tuple(const_positions)
         self.vec_positions = tuple(k for k in range(num_args)
                                    if k not in self.const_positions)
@@ -116,6 +117,20 @@ class _MatrixFunction(object):
             vec.append(v)
         cst = [float(num_args[k]) for k in self.const_positions]
         if n > 0:
+            if on_device:
+                # Stream contract of the device path: the launch is enqueued
+                # on torch's CURRENT stream of the result's device -- ordered
+                # after whatever produced the argument tensors there and
+                # before whatever reads `result` there -- and is asynchronous
+                # like any torch operation.  (The handle's own stream is not
+                # ordered with torch's: a caller would read stale inputs or an
+                # unfinished result.)
+                import torch
+                self._hip.use_torch_stream(
+                    torch.cuda.current_stream(result.device))
+            elif self._on_torch_stream:
+                self._hip.set_stream(None)      # host path: own stream, sync
+            self._on_torch_stream = bool(on_device)
             self._hip.evaluate(result, vec, cst, n,
                                hb.DEVICE if on_device else hb.HOST)
         return result.reshape(n, rows, cols)
@@ -133,8 +148,10 @@ def ufuncify_matrix(args, expr, const=None, tmp_dir=None, parallel=False,
     [reduced_matrix])``, ``:677-682``); ``const``: those of ``args`` that are
     passed as floats (one value per call) instead of ``(n,)`` arrays.
     ``result`` is the caller's C-contiguous float64 ``(n, rows*cols)`` array
-    (NumPy: evaluated through PCIe; a CUDA ``torch`` tensor with CUDA tensor
-    arguments: evaluated in place on the handle's stream).
+    (NumPy: evaluated through PCIe, synchronous; a CUDA ``torch`` tensor with
+    CUDA tensor arguments: evaluated in place, enqueued on torch's current
+    stream of that device -- ordered with the torch operations around it and
+    asynchronous like them).
 
     ``tmp_dir`` is the code-object cache directory, ``parallel`` is accepted
     and ignored (a launch is always parallel); ``device`` (HIP ordinal) and

@@ -57,15 +57,18 @@ def collocator(small, nodes, launch_nodes, lower_small):
 
 
 def prebuild(names):
-    jobs = []
+    jobs, seen = [], set()
     with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as pool:
         for label, small, nodes, w, ln in launches(names):
             col = collocator(small, nodes, ln, True)
             prog = col._build_program()
             cands, _ = launch_plan.candidates(prog, (ln + 63)//64)
             for tag, kw in cands:
-                source, _ = emit_module(prog, EmitOptions(**kw),
-                                        node_blocks=(ln + 63)//64)
+                source, meta = emit_module(prog, EmitOptions(**kw),
+                                           node_blocks=(ln + 63)//64)
+                if meta['sha'] in seen:
+                    continue
+                seen.add(meta['sha'])
                 jobs.append((label, w, tag,
                              pool.submit(hb.compile_module, source)))
         for label, w, tag, job in jobs:
