@@ -1,0 +1,128 @@
+"""Seeded generator of small direct-collocation problems for fuzzed parity
+tests (test infrastructure): n <= 6 states with names chosen to trap
+name-sorting, known and unknown parameters and input trajectories, both
+discretisations, fixed or variable duration, M = n or n + 1 equations, 1-3
+instance constraints (single atoms, two-atom pairs, input atoms) and
+expressions drawn from every function the product lowers and the oracle's C
+printer accepts, kept inside their domains for free vectors in [-1, 1).
+
+``generate(seed)`` returns the keyword dict both ``opty_amd.
+ConstraintCollocator`` and the oracle accept."""
+import numpy as np
+import sympy as sm
+
+STATE_NAMES = ['a10', 'a2', 'b', 'a1', 'c3', 'c20', 'B']
+INPUT_NAMES = ['f10', 'f2', 'u', 'F']
+KNOWN_TRAJ_NAMES = ['w2', 'w10']
+PAR_NAMES = ['p2', 'p10', 'k', 'm1', 'M']
+
+
+def _unary_pool(rng):
+    """(callable x -> expression) with |x| <~ 3 safe."""
+    half = sm.Rational(1, 2)
+    return [
+        sm.sin, sm.cos, lambda x: sm.tan(x/4), lambda x: sm.exp(-x**2/4),
+        lambda x: sm.log(2 + x**2), lambda x: sm.sqrt(1 + x**2),
+        sm.tanh, lambda x: sm.sinh(x/2), lambda x: sm.cosh(x/3), sm.atan,
+        lambda x: sm.asin(sm.tanh(x)/2), lambda x: sm.acos(sm.tanh(x)/2),
+        lambda x: sm.erf(x/2), lambda x: sm.asinh(x),
+        lambda x: (sm.Rational(7, 2) + x)**sm.Rational(3, 2),
+        lambda x: x**3, lambda x: x**2, lambda x: 1/(1 + x**2),
+        lambda x: sm.Abs(x - half),
+        lambda x: sm.Piecewise((x**2, x > half/2), (x/4, True)),
+        lambda x: sm.Piecewise((sm.Integer(0), sm.And(x > -half, x < half)),
+                               (x - half, x >= half), (x + half, True)),
+    ]
+
+
+def _expr(rng, atoms, pars, depth=0):
+    pool = _unary_pool(rng)
+    kind = rng.integers(0, 7 if depth < 2 else 3)
+    pick = lambda seq: seq[int(rng.integers(0, len(seq)))]
+    if kind == 0 or not atoms:
+        return pick(atoms) if atoms else sm.Integer(1)
+    if kind == 1:
+        c = sm.Rational(int(rng.integers(-8, 9)) or 3, 4)
+        return c*pick(atoms)
+    if kind == 2:
+        return pick(pool)(pick(atoms))
+    if kind == 3:
+        return _expr(rng, atoms, pars, depth + 1) * \
+            _expr(rng, atoms, pars, depth + 1)
+    if kind == 4:
+        return _expr(rng, atoms, pars, depth + 1) + \
+            (pick(pars) if pars else 1)*_expr(rng, atoms, pars, depth + 1)
+    if kind == 5:
+        # (no Piecewise inside Max / Min: SymPy 1.14 prints the Heaviside of
+        # their derivative with only the FIRST branch of an inner Piecewise --
+        # the oracle's, and the reference's, C code is then wrong where the
+        # other branch applies; seed 20 of an earlier version of this
+        # generator found it, the product's value was the right one)
+        a, b = pick(pool[:-2])(pick(atoms)), pick(atoms)
+        return pick([sm.Max(a, b), sm.Min(a, b), sm.atan2(a, 3 + b)])
+    return pick(pool)(_expr(rng, atoms, pars, depth + 1)/2)
+
+
+def generate(seed):
+    rng = np.random.default_rng(1000 + seed)
+    t = sm.Symbol('t')
+    n = int(rng.integers(1, 7))
+    names = list(rng.permutation(STATE_NAMES))[:n]
+    states = [sm.Function(nm)(t) for nm in names]
+    q = int(rng.integers(0, 3))
+    unknown_in = [sm.Function(nm)(t) for nm in
+                  list(rng.permutation(INPUT_NAMES))[:q]]
+    mk = int(rng.integers(0, 3))
+    known_in = [sm.Function(nm)(t) for nm in KNOWN_TRAJ_NAMES[:mk]]
+    npar = int(rng.integers(1, 5))
+    pars = [sm.Symbol(nm, real=True) for nm in
+            list(rng.permutation(PAR_NAMES))[:npar]]
+    nknown = int(rng.integers(0, npar + 1))
+    known_pars = pars[:nknown]
+    method = 'backward euler' if rng.integers(0, 2) else 'midpoint'
+    variable = bool(rng.integers(0, 2))
+    N = int(rng.integers(5, 140))
+    atoms = states + unknown_in + known_in
+    eqs = []
+    for j, x in enumerate(states):
+        mass = 1 + (pars[0]**2 if j % 2 else sm.Integer(1)) * \
+            (states[(j + 1) % n]**2 if rng.integers(0, 2) else 1)/4
+        eqs.append(mass*x.diff(t) - _expr(rng, atoms, pars))
+    if rng.integers(0, 3) == 0:                     # an algebraic equation
+        eqs.append(_expr(rng, atoms, pars) - states[0])
+    eom = sm.Matrix(eqs)
+    # every declared symbol must occur (the reference rejects known symbols
+    # that are not in the equations)
+    used = eom.free_symbols | {f for f in eom.atoms(sm.Function)}
+    for k, s in enumerate(pars + unknown_in + known_in):
+        if s not in used:
+            eom[k % len(eqs)] += s*sm.Rational(1, 3)
+    h = sm.Symbol('hh', real=True) if variable else \
+        float(rng.integers(1, 9))/64.0
+    dur = (N - 1)*h
+    t0 = 0*h if variable else 0.0
+    inst = []
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.integers(0, 3)
+        x = states[int(rng.integers(0, n))]
+        if kind == 0 or (kind == 2 and not unknown_in):
+            inst.append(x.func(t0) - sm.Rational(int(rng.integers(-3, 4)), 4))
+        elif kind == 1:
+            y = states[int(rng.integers(0, n))]
+            inst.append(x.func(t0) - sm.Rational(3, 2)*y.func(dur))
+        else:
+            u = unknown_in[int(rng.integers(0, len(unknown_in)))]
+            inst.append(u.func(dur)*x.func(dur) - u.func(t0))
+    grid = np.linspace(0.0, 1.0, N)
+    traj_map = {f: np.cos(3.0*grid + k) for k, f in enumerate(known_in)}
+    par_map = {p: 0.5 + 0.25*k for k, p in enumerate(known_pars)}
+    return dict(equations_of_motion=eom, state_symbols=tuple(states),
+                num_collocation_nodes=N, node_time_interval=h,
+                known_parameter_map=par_map, known_trajectory_map=traj_map,
+                instance_constraints=tuple(inst), time_symbol=t,
+                integration_method=method)
+
+
+#: seeds of the fuzzed parity test (tests/test_fuzz_parity.py); build()
+#: prebuilds their code objects and oracle libraries
+SEEDS = tuple(range(36))
