@@ -138,6 +138,12 @@ def candidates(prog, node_blocks):
     for j in _neighbours(g['jac'], low, top):
         if j != g['jac']:
             out.append(('jac=%d' % j, dict(seed, groups=j)))
+    if g['chunk'] == 32 and not g['occupancy']:
+        # shorter ring tiles (16-entry chunks) leave LDS for wider workgroups
+        # that share one input slab: fewer slab fills per block, which large
+        # slabs (50-state systems) and short launches (node shards) may prefer
+        out.append(('c16', dict(seed, chunk=16)))
+        out.append(('c16w4', dict(seed, chunk=16, waves=4)))
     return out, g
 
 
@@ -207,7 +213,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
             if not times[what][k]:
                 continue
             ms = float(np.median(times[what][k]))
-            tag = label if label in ('seed', 'chunk') else label.split('=')[1]
+            tag = label.split('=')[1] if '=' in label else label
             if label == 'seed':
                 tag = str(geo['fused'] if what == 'fused' else geo['jac'])
             measured[what][tag] = ms
@@ -218,12 +224,20 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
             if log:
                 log('%-10s %-6s %.4f ms' % (label, what, ms))
     if geo['line_mode']:
-        options = dict(built[0][1])
-        options['fused_groups'] = best['fused'][2]['fused_groups']
-        options['groups'] = best['jac'][2]['groups']
+        # the fused kernel (what a solver's pair and the benchmark's step
+        # cost) picks the shape (chunk / workgroup width / its strips); the
+        # Jacobian-only kernel then takes the best strip count measured with
+        # that shape
+        options = dict(best['fused'][2])
+        shape = lambda kw: (kw.get('chunk', 32), kw.get('waves'))
+        same = [(float(np.median(times['jac'][k])), kw)
+                for k, (label, kw, _, _) in enumerate(built)
+                if times['jac'][k] and shape(kw) == shape(options)]
+        if same:
+            options['groups'] = min(same, key=lambda t: t[0])[1]['groups']
     else:
         # small blocks: the only choice is how the tile is flushed; the fused
-        # kernel (what a solver's pair costs) decides
+        # kernel decides
         options = dict(small_flush='chunk') \
             if best['fused'][1] == 'chunk' else {}
     sha = problem_sha(prog)
