@@ -276,31 +276,17 @@ __device__ __forceinline__ void opty_head_piece(const double *tile,
 //     is good to an ulp of r itself, also next to multiples of pi/2), then the
 //     classic minimax kernels on [-pi/4, pi/4] (coefficients of the public
 //     fdlibm k_sin.c / k_cos.c, < 1 ulp each) and a branch-free quadrant fix;
-//     ~35 double-precision instructions for the pair;
+//     ~50 vector instructions for the pair (the compiler's two-address
+//     v_fmac_f64 needs every Horner constant copied into a VGPR pair first;
+//     a three-address v_fma_f64 with the constant in SGPRs, forced through
+//     inline assembly, saved those copies but returned non-repeatable values
+//     in one equation of the 24-link row-sorted module, next to hundreds of
+//     SGPR spills -- not pursued: the kernels do not wait on the vector ALU);
 //   otherwise (and Inf) : the library sincos, in a branch marked unlikely so
 //     that its code sits behind the kernel's hot path (a real call would
 //     need a stack, i.e. scratch memory, in every kernel).
 // NaN falls through the fast path and stays NaN.
 // ---------------------------------------------------------------------------
-// d = a*b + k with the constant k read from a scalar register pair.  The
-// compiler's own choice for fma(z, p, K) is the two-address v_fmac_f64, whose
-// addend K must first be copied into a VGPR pair: two v_mov_b32 per Horner
-// step, each as long on the vector ALU as the multiply-add itself.  The
-// three-address form takes K straight from SGPRs (filled by s_mov on the
-// scalar unit, in the shadow of the vector work).
-#ifndef OPTY_TRIG_ASM
-#define OPTY_TRIG_ASM 1
-#endif
-__device__ __forceinline__ double opty_fma_k(double a, double b, double k) {
-#if OPTY_TRIG_ASM
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
-    return d;
-#else
-    return __builtin_fma(a, b, k);
-#endif
-}
-
 __device__ __forceinline__ void opty_sincos(double x, double *s, double *c) {
     if (__builtin_expect(!(__builtin_fabs(x) <= 1048576.0) && x == x, 0)) {
         sincos(x, s, c);
@@ -315,17 +301,17 @@ __device__ __forceinline__ void opty_sincos(double x, double *s, double *c) {
     // sin(r) = r + r^3*(S1 + z*(S2 + ... z*S6))
     // (innermost step as multiply + add: one scalar constant per instruction)
     double ps = z*1.58969099521155010221e-10 + -2.50507602534068634195e-08;
-    ps = opty_fma_k(z, ps, 2.75573137070700676789e-06);
-    ps = opty_fma_k(z, ps, -1.98412698298579493134e-04);
-    ps = opty_fma_k(z, ps, 8.33333333332248946124e-03);
-    ps = opty_fma_k(z, ps, -1.66666666666666324348e-01);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
     const double sr = __builtin_fma(z*r, ps, r);
     // cos(r) = w + (((1 - w) - z/2) + z*z*(C1 + z*(C2 + ... z*C6))), w = 1 - z/2
     double pc = z*-1.13596475577881948265e-11 + 2.08757232129817482790e-09;
-    pc = opty_fma_k(z, pc, -2.75573143513906633035e-07);
-    pc = opty_fma_k(z, pc, 2.48015872894767294178e-05);
-    pc = opty_fma_k(z, pc, -1.38888888888741095749e-03);
-    pc = opty_fma_k(z, pc, 4.16666666666666019037e-02);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
     const double hz = 0.5*z;
     const double w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + (z*z)*pc);

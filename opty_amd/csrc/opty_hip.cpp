@@ -212,8 +212,12 @@ public:
         stop();
         n = std::max(1, std::min(n, 256));
         quit_ = false;
+        // the epoch the new workers have seen is fixed HERE, by the thread
+        // that also starts the jobs: a worker that read it on its own could
+        // start late, after the first job was posted, and sleep through it
+        const unsigned long long seen = epoch_;
         for (int t = 0; t < n; ++t)
-            workers_.emplace_back([this, t, n] { work(t, n); });
+            workers_.emplace_back([this, t, n, seen] { work(t, n, seen); });
     }
 
     // The caller publishes chunks [0, c) as landed with ready(c) and finally
@@ -247,12 +251,7 @@ private:
         workers_.clear();
     }
 
-    void work(int t, int T) {
-        unsigned long long seen = 0;
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            seen = epoch_;
-        }
+    void work(int t, int T, unsigned long long seen) {
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(m_);
