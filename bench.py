@@ -250,9 +250,13 @@ def other_configs(dev, iters):
 
 def host_path(kw, dev_index, reps=7):
     """Wall time of the host (cyipopt-callback) path of config 3: NumPy in,
-    NumPy out through ``generate_*_function`` (PCIe inclusive), for the
-    reference's dense-block pattern and for ``prune_zeros=True``."""
+    NumPy out through ``generate_*_function`` (PCIe inclusive): the
+    reference's dense-block contract as the callbacks serve it (``jac``:
+    after the first call only the entries that can change cross PCIe,
+    ``opty_hip_eval_jac_persistent``), the same vector copied whole every call
+    (``jac_dense_copy``), and ``prune_zeros=True``."""
     import opty_amd
+    from opty_amd import hip_backend as hb
     from examples import problems
 
     def med(fn, frees):
@@ -270,6 +274,14 @@ def host_path(kw, dev_index, reps=7):
         frees = [problems.make_free(col.num_free, seed=s) for s in range(3)]
         if not label:
             out['con'] = med(col.generate_constraint_function(), frees)
+            dense = hb.pinned_empty(col.hip.nnz)
+            out['jac_dense_copy'] = med(
+                lambda f: col.hip.eval_jac(f, dense, hb.HOST), frees)
+            del dense
+            from opty_amd.codegen.program import varying_entries
+            out['varying_entries_per_block'] = len(varying_entries(
+                col._build_program()))
+            out['host_threads'] = hb.host_threads()
         out['jac' + label] = med(col.generate_jacobian_function(), frees)
         out['nnz' + label] = col.hip.nnz
         col.hip.close()
