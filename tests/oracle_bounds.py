@@ -63,13 +63,12 @@ class _Evaluator(object):
                 np.abs(bv), 1e-300) + np.abs(np.log(np.abs(bv) + 1e-300))*pm)
         if isinstance(e, sm.Piecewise):
             vals = [self(x) for x, _ in e.args]
-            conds = [self._cond(c) for _, c in e.args]
-            v = np.select(conds, [np.broadcast_to(x[0], np.shape(conds[0]))
-                                  if np.ndim(conds[0]) else x[0]
-                                  for x in vals])
-            m = np.select(conds, [np.broadcast_to(x[1], np.shape(conds[0]))
-                                  if np.ndim(conds[0]) else x[1]
-                                  for x in vals])
+            conds = [np.asarray(self._cond(c)) for _, c in e.args]
+            shape = np.broadcast(*(conds + [np.asarray(x[0]) for x in vals] +
+                                   [np.asarray(x[1]) for x in vals])).shape
+            conds = [np.broadcast_to(c, shape) for c in conds]
+            v = np.select(conds, [np.broadcast_to(x[0], shape) for x in vals])
+            m = np.select(conds, [np.broadcast_to(x[1], shape) for x in vals])
             return v, m
         if isinstance(e, (sm.Max, sm.Min)):
             parts = [self(a) for a in e.args]
@@ -82,14 +81,15 @@ class _Evaluator(object):
             args = [self(a) for a in e.args]
             fn = sm.lambdify(sm.symbols('x0:%d' % len(args)),
                              e.func(*sm.symbols('x0:%d' % len(args))),
-                             'numpy')
+                             ['scipy', 'numpy'])
             with np.errstate(all='ignore'):
                 v = fn(*[a[0] for a in args])
                 m = np.abs(v)
                 xs = sm.symbols('x0:%d' % len(args))
                 for k, a in enumerate(args):
                     try:
-                        d = sm.lambdify(xs, e.func(*xs).diff(xs[k]), 'numpy')
+                        d = sm.lambdify(xs, e.func(*xs).diff(xs[k]),
+                                        ['scipy', 'numpy'])
                         dv = np.abs(d(*[b[0] for b in args]))
                     except Exception:
                         dv = 1.0

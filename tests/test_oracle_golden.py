@@ -161,3 +161,32 @@ def test_reference_unit_test_fixtures(name):
         np.testing.assert_array_equal(cols, case['cols'])
     np.testing.assert_allclose(dense_from_coo(jac, rows, cols),
                                case['dense'], rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize('name', gu.FULL_FAST)
+def test_tolerance_floors_are_justified_by_the_oracle(name):
+    """The per-entry floors of the parity tolerance come from a running
+    rounding-error bound of the PRODUCT's expression DAG
+    (``golden_util.error_bounds``); a numerically poor rewrite there could
+    widen its own tolerance.  Hold them to an independent measure: the term
+    magnitudes of the ORACLE's SymPy expressions (``tests/oracle_bounds.py``:
+    every sum adds absolute values) -- no entry's bound may exceed 32 of them
+    (measured over the fixtures: 1.0 ... 14.6) -- and the reference's values
+    themselves must not exceed their own term magnitudes."""
+    import opty_amd
+    import oracle_bounds
+    meta, z = gu.load(name)
+    kw = problems.build(name)
+    orc = OracleCollocator(name=name.replace('_small', ''), **kw)
+    orc.generate_jacobian_function()(z['free'])
+    cmag, jmag = oracle_bounds.magnitudes(orc, z['free'])
+    col = opty_amd.ConstraintCollocator(**kw)
+    cb, jb = gu.error_bounds(col, z['free'])
+    N1, M, C = meta['N'] - 1, meta['M'], meta['C']
+    for bound, mag, ref, what in (
+            (cb[:M*N1], cmag, z['con'][:M*N1], 'con'),
+            (jb[:M*C*N1], jmag, z['jac'][:M*C*N1], 'jac')):
+        assert np.isfinite(mag).all(), what
+        assert (np.abs(ref) <= mag*(1 + 1e-12) + 1e-300).all(), what
+        assert (bound <= 32.0*mag + 1e-300).all(), (
+            what, float(np.max(bound/np.maximum(mag, 1e-300))))
