@@ -874,13 +874,34 @@ class _ModuleWriter(object):
         slab_of = {r: k for k, r in enumerate(rows)}
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
         if W is None:
-            W = self._waves_per_workgroup(len(rows), ring_rows)
+            if G <= 4 and any(con_of_group) and \
+                    any(e1 > e0 for grp in groups for e0, e1 in grp):
+                # the fused kernel of a small block: its few waves form ONE
+                # workgroup -- one slab fill, and the constraint wave rides in
+                # the Jacobian wave's LDS instead of reserving a ring tile it
+                # never uses in a workgroup of its own
+                W = G
+            else:
+                W = self._waves_per_workgroup(len(rows), ring_rows)
         W = max(1, min(W, G))
         sets = (G + W - 1)//W
         bodies = [self._group_body(grp, con_of_group[g], slab_of)
                   if keep[g] else []
                   for g, grp in enumerate(groups)]
-        lds_doubles = max(1, (len(rows) + W*ring_rows)*TS)
+        # Ring tiles only for the waves that stage Jacobian entries: the
+        # constraint waves come last, so in every workgroup the ring users
+        # are its first waves (tile index == wave index) and a workgroup of
+        # [Jacobian wave, constraint wave] -- the fused kernel of a small
+        # block -- holds one tile, not two.
+        users = [any(e1 > e0 for e0, e1 in grp) for grp in groups]
+        rings = 0
+        for w0 in range(0, G, W):
+            mine = users[w0:w0 + W]
+            assert mine == sorted(mine, reverse=True), 'ring users first'
+            rings = max(rings, sum(mine))
+        if W == 1:
+            rings = 1           # one size per kernel: nothing to share
+        lds_doubles = max(1, (len(rows) + rings*ring_rows)*TS)
         occ = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (
             self.o.occupancy, self.o.occupancy) if self.o.occupancy else ''
         src = ['extern "C" __global__ void __launch_bounds__(%d)%s'

@@ -742,7 +742,7 @@ def test_small_launch_geometry_matches_default(overrides, N, explicit):
 
 @pytest.mark.parametrize('name,N', [('config3_10link', 20001),
                                     ('config2_pendulum', 100001),
-                                    ('pend2_link_vardur_unkmass_small', 9001)])
+                                    ('pend2_link_vardur_unkmass_small', 12001)])
 def test_persistent_jacobian_moves_only_what_changed(name, N):
     """``jacobian(free)`` through ``opty_hip_eval_jac_persistent`` (varying
     entries packed, copied in chunks, scattered by the host thread pool) is
