@@ -202,9 +202,10 @@ def other_configs(dev, iters):
     from opty_amd import hip_backend as hb
     from examples import problems
     out = {}
-    for name in ('config2_pendulum', 'config5_standin_24link'):
-        col = opty_amd.ConstraintCollocator(device=dev.index,
-                                            **problems.build(name))
+    for name in ('config2_pendulum', 'config5_standin_24link',
+                 'config5_gaitlike_24link'):
+        pkw = problems.build(name)
+        col = opty_amd.ConstraintCollocator(device=dev.index, **pkw)
         hip = col.hip
         hip.use_torch_stream()
         free = torch.from_numpy(problems.make_free(
@@ -223,6 +224,30 @@ def other_configs(dev, iters):
             nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
             fused_algorithmic_bytes=nbytes,
             fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
+        if name.startswith('config5'):
+            # one of eight node shards of the same problem (what each GPU of
+            # an 8-GPU node launches): its own launch geometry, the global
+            # free vector, a node range from the middle
+            from opty_amd.sharded import partition_nodes
+            ncn = col.num_collocation_nodes - 1
+            a, b = partition_nodes(ncn, 8)[3]
+            shard = opty_amd.ConstraintCollocator(
+                device=dev.index, launch_nodes=b - a, **pkw)
+            shard._program = col._program            # same equations
+            sh = shard.hip
+            sh.use_torch_stream()
+            prog = col._build_program()
+            scon = torch.empty((prog.M, b - a), dtype=torch.float64,
+                               device=dev)
+            sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a, jac, a, b,
+                               max(3, iters//4))
+            ms = min(sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a,
+                                        jac, a, b, iters) for _ in range(3))
+            out[name]['shard_1of8'] = dict(
+                nodes=b - a, fused_ms=ms,
+                speedup_vs_whole=res['opty_conjac']/ms)
+            sh.close()
+            del scon
         if name == 'config2_pendulum':
             # the cyipopt-callback path of the small config (NumPy in / out,
             # PCIe and sync latency inclusive); the reference's compiled C

@@ -222,7 +222,10 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
             # width / workgroup width) by more than box-to-box spread
             margin = 0.0 if label == 'seed' else (
                 0.01 if '=' in label else 0.03)
-            if what not in best or ms < best[what][0]*(1.0 - margin):
+            # ... and by more than the resolution of a microsecond-scale
+            # launch
+            if what not in best or (ms < best[what][0]*(1.0 - margin) and
+                                    ms < best[what][0] - 3e-4):
                 best[what] = (ms, label, kw)
             if log:
                 log('%-10s %-6s %.4f ms' % (label, what, ms))

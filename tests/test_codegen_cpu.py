@@ -171,7 +171,7 @@ def test_problem_facade_bounds_without_ipopt():
                 kw['state_symbols'], 5, 1.0)
 
 
-def test_emit_builds_for_gfx950(tmp_path):
+def test_emit_builds_for_gfx950(tmp_path, monkeypatch):
     """The printed HIP for the 10-link pendulum cross-compiles for gfx950 with
     zero scratch (no register spills to memory) in the Jacobian kernels."""
     if shutil.which('hipcc') is None and not os.path.exists(
@@ -184,9 +184,18 @@ def test_emit_builds_for_gfx950(tmp_path):
         assert 'void __launch_bounds__(64)\n%s(' % kern in source
     hsaco = hb.compile_module(source, cache_dir=str(tmp_path))
     assert os.path.getsize(hsaco) > 0
-    # N does not enter the generated code: one code object serves every N
+    # N does not enter the generated code: with the printer's own rules one
+    # code object serves every large N ...
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', 'off')
     col2 = ConstraintCollocator(**problems.build('config3_10link'))
     assert col2.generate_source()[1]['sha'] == meta['sha']
+    # ... and a measured launch plan (opty_amd/launch_plans.json) only moves
+    # the strip counts: the fused kernel of BASELINE config 3 keeps the seed
+    monkeypatch.delenv('OPTY_LAUNCH_PLANS')
+    col3 = ConstraintCollocator(**problems.build('config3_10link'))
+    meta3 = col3.generate_source()[1]
+    assert meta3['kernels']['conjac']['sha'] == meta['kernels']['conjac']['sha']
+    assert meta3['P'] == meta['P']
 
 
 def test_group_ranges_cover_block():
