@@ -178,8 +178,20 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
                                  int32_t count);
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
                                  double *jac);
+/* The same for one node shard of a problem evaluated by several GPUs: the
+ * blocks of the constraint nodes [node_begin, node_end), as
+ * opty_hip_eval_shard left them in device memory (d_jac_shard), go into the
+ * slice [node_begin*P, node_end*P) of the dense HOST vector of the GLOBAL
+ * problem (host_jac: the shared page-locked vector every rank copies its
+ * shard into, SURVEY.md 8(e) "direct-to-host") -- all of them the first
+ * time, later only the varying entries.  Synchronous; runs on the handle's
+ * stream behind the evaluation. */
+int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
+                               double *host_jac, int64_t node_begin,
+                               int64_t node_end);
 /* Host threads of the scatter pool (per process; 0 = the default:
- * OPTY_HIP_HOST_THREADS or min(16, hardware threads / 2)). */
+ * OPTY_HIP_HOST_THREADS, or min(16, hardware threads / 2 / LOCAL_WORLD_SIZE)
+ * -- the ranks of a node share its cores). */
 int opty_hip_set_host_threads(int32_t count);
 int opty_hip_host_threads(void);
 

@@ -202,8 +202,12 @@ public:
             const int n = atoi(env);
             if (n > 0) return std::min(n, 256);
         }
+        // one pool per process: the ranks of a node share its cores
+        unsigned ranks = 1;
+        if (const char *env = getenv("LOCAL_WORLD_SIZE"))
+            ranks = (unsigned)std::max(1, atoi(env));
         const unsigned hw = std::thread::hardware_concurrency();
-        return (int)std::max(1u, std::min(16u, hw/2));
+        return (int)std::max(2u, std::min(16u, hw/2/ranks));
     }
 
     int threads() const { return (int)workers_.size(); }
@@ -319,8 +323,12 @@ struct opty_hip_problem {
     // page-locked, device-mapped staging of the latency path (eval_mapped)
     double *h_free = nullptr, *h_con = nullptr, *h_jac = nullptr;
     std::vector<hipEvent_t> chunk_events;
+    size_t packed_cap = 0;                // doubles in d_packed / h_packed
     const double *static_host = nullptr;  // vector whose invariant entries
     bool static_valid = false;            // ... are up to date
+    const double *shard_host = nullptr;   // the same for a node shard copied
+    long long shard_begin = 0, shard_end = 0;   // by opty_hip_shard_jac_to_host
+    bool shard_valid = false;
 
     int64_t ncon_nodes() const { return d.N - 1; }
     int64_t P() const { return (int64_t)d.P; }
@@ -1085,7 +1093,7 @@ int opty_hip_set_known_parameters(opty_hip_problem *p, const double *values,
                            hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     p->uni_dirty = true;
-    p->static_valid = false;    // node-invariant Jacobian entries change
+    p->static_valid = p->shard_valid = false;   // invariant entries change
     p->have_params = true;
     return 0;
 }
@@ -1098,7 +1106,7 @@ int opty_hip_set_interval(opty_hip_problem *p, double h) {
     p->h = h;
     p->have_h = true;
     p->uni_dirty = true;
-    p->static_valid = false;
+    p->static_valid = p->shard_valid = false;
     return 0;
 }
 
@@ -1421,56 +1429,45 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
         HIP_TRY(hipMemcpy(p->d_var, entries, count*sizeof(int),
                           hipMemcpyHostToDevice));
     }
-    p->static_valid = false;
+    p->static_valid = p->shard_valid = false;
     return 0;
 }
 
-int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
-                                 double *jac) {
-    if (!p) return fail("null handle");
-    if (!free_ || !jac) return fail("null buffer");
-    if (int rc = use_device(p)) return rc;
-    if (int rc = check_ready(p)) return rc;
+// Moves the dense blocks of `count` nodes from device memory (d_blocks) into
+// host memory (h_blocks, page-locked): all of it (`full`), or only the varying
+// entries -- packed on the device, copied in chunks, scattered by the host
+// threads while the next chunk is in flight.  Synchronous.
+static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
+                               double *h_blocks, long long count, bool full) {
     const int V = (int)p->var_entries.size();
-    const long long P = p->P(), ncn = p->ncon_nodes();
-    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
-    if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
-    if (int rc = order_streams(p)) return rc;
-    HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
-                           hipMemcpyHostToDevice, p->stream));
-    if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
-                             p->d_jac, whole(p), true))
-        return rc;
-    const bool full = !p->static_valid || p->static_host != jac ||
-                      p->d.layout != OPTY_HIP_LAYOUT_COO || p->d_var == nullptr
-                      || 2*V > P;     // nothing to gain: dense copy
+    const long long P = p->P();
+    if (count <= 0) return 0;
     if (full) {
-        HIP_TRY(hipMemcpyAsync(jac, p->d_jac, p->nnz()*sizeof(double),
+        HIP_TRY(hipMemcpyAsync(h_blocks, d_blocks,
+                               (size_t)count*P*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
-        p->static_host = jac;
-        p->static_valid = p->d_var != nullptr || V == 0;
         return 0;
     }
-    if (V == 0) {       // a block of constants: only the instance tail moves
-        if (p->d.nnz_inst > 0)
-            HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
-                                   p->d.nnz_inst*sizeof(double),
-                                   hipMemcpyDeviceToHost, p->stream));
+    if (V == 0) return 0;       // a block of constants: nothing moves
+    const size_t packed = (size_t)count*V;
+    if (packed > p->packed_cap) {
         HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
-        return 0;
-    }
-    const size_t packed = (size_t)ncn*V;
-    if (int rc = ensure(&p->d_packed, packed)) return rc;
-    if (!p->h_packed)
+        if (p->d_packed) (void)hipFree(p->d_packed);
+        if (p->h_packed) (void)hipHostFree(p->h_packed);
+        p->d_packed = p->h_packed = nullptr;
+        p->packed_cap = 0;
+        HIP_TRY(hipMalloc((void **)&p->d_packed, packed*sizeof(double)));
         HIP_TRY(hipHostMalloc((void **)&p->h_packed, packed*sizeof(double),
                               hipHostMallocDefault));
+        p->packed_cap = packed;
+    }
     // chunks of about 16 MB: long enough for the DMA engine's full rate,
     // short enough that the host threads start early and finish soon after
     // the last byte has landed
     int chunks = (int)std::max<size_t>(1, std::min<size_t>(
         32, packed*sizeof(double)/(16u << 20)));
-    chunks = (int)std::min<long long>(chunks, ncn);
+    chunks = (int)std::min<long long>(chunks, count);
     while ((int)p->chunk_events.size() < chunks) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1480,31 +1477,27 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
         ((long long)packed + 255)/256, 8192);
     (void)hipGetLastError();
     hipLaunchKernelGGL(opty_pack_kernel, dim3(grid), dim3(256), 0, p->stream,
-                       p->d_jac, p->d_packed, p->d_var, V, P,
+                       d_blocks, p->d_packed, p->d_var, V, P,
                        (long long)packed);
     HIP_TRY(hipGetLastError());
     for (int c = 0; c < chunks; ++c) {
-        const long long a = ncn*c/chunks, b = ncn*(c + 1)/chunks;
+        const long long a = count*c/chunks, b = count*(c + 1)/chunks;
         HIP_TRY(hipMemcpyAsync(p->h_packed + a*V, p->d_packed + a*V,
                                (size_t)(b - a)*V*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
     }
-    if (p->d.nnz_inst > 0)
-        HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
-                               p->d.nnz_inst*sizeof(double),
-                               hipMemcpyDeviceToHost, p->stream));
     ScatterPool &pool = ScatterPool::instance();
     ScatterPool::Job job;
     job.packed = p->h_packed;
-    job.dense = jac;
+    job.dense = h_blocks;
     job.run_start = p->run_start.data();
     job.run_len = p->run_len.data();
     job.nruns = (int)p->run_start.size();
     job.V = V;
     job.chunks = chunks;
     job.P = P;
-    job.nodes = ncn;
+    job.nodes = count;
     pool.start(job);
     int rc = 0;
     for (int c = 0; c < chunks; ++c) {
@@ -1516,11 +1509,73 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
         pool.ready(c + 1);      // also after a failure: the workers must end
     }
     pool.wait();
-    if (rc) {
+    return rc;
+}
+
+// nothing to gain from packing: no table, or most of the block varies
+static bool packing_pays(const opty_hip_problem *p) {
+    return p->d.layout == OPTY_HIP_LAYOUT_COO && p->d_var != nullptr &&
+           2*(long long)p->var_entries.size() <= p->P();
+}
+
+int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
+                                 double *jac) {
+    if (!p) return fail("null handle");
+    if (!free_ || !jac) return fail("null buffer");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = check_ready(p)) return rc;
+    const long long P = p->P(), ncn = p->ncon_nodes();
+    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+    if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
+    if (int rc = order_streams(p)) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
+                           hipMemcpyHostToDevice, p->stream));
+    if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
+                             p->d_jac, whole(p), true))
+        return rc;
+    const bool full = !p->static_valid || p->static_host != jac ||
+                      !packing_pays(p);
+    if (p->d.nnz_inst > 0)
+        HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
+                               p->d.nnz_inst*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full)) {
         p->static_valid = false;
         return rc;
     }
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    p->static_host = jac;
+    p->static_valid = true;
+    return 0;
+}
+
+int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
+                               double *host_jac, int64_t node_begin,
+                               int64_t node_end) {
+    if (!p) return fail("null handle");
+    if (!d_jac_shard || !host_jac) return fail("null buffer");
+    if (node_begin < 0 || node_end < node_begin ||
+        node_end > p->ncon_nodes())
+        return fail("shard [%lld, %lld) outside the %lld constraint nodes",
+                    (long long)node_begin, (long long)node_end,
+                    (long long)p->ncon_nodes());
+    if (p->d.layout != OPTY_HIP_LAYOUT_COO)
+        return fail("the CSR layout is not node-sharded");
+    if (int rc = use_device(p)) return rc;
+    if (int rc = order_streams(p)) return rc;
+    const bool full = !p->shard_valid || p->shard_host != host_jac ||
+                      p->shard_begin != node_begin ||
+                      p->shard_end != node_end || !packing_pays(p);
+    if (int rc = move_blocks_to_host(p, d_jac_shard,
+                                     host_jac + node_begin*p->P(),
+                                     node_end - node_begin, full)) {
+        p->shard_valid = false;
+        return rc;
+    }
+    p->shard_host = host_jac;
+    p->shard_begin = node_begin;
+    p->shard_end = node_end;
+    p->shard_valid = true;
     return 0;
 }
 

@@ -197,6 +197,8 @@ _SIGNATURES = {
     'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_set_varying_entries': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
     'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P]),
+    'opty_hip_shard_jac_to_host': (ctypes.c_int, [
+        _P, _P, _P, ctypes.c_int64, ctypes.c_int64]),
     'opty_hip_set_host_threads': (ctypes.c_int, [ctypes.c_int32]),
     'opty_hip_host_threads': (ctypes.c_int, []),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
@@ -413,6 +415,13 @@ class HipProblem(object):
         persistent host ``jac``."""
         _check(self._lib.opty_hip_eval_jac_persistent(
             self._h, _ptr(free), _ptr(jac)))
+
+    def shard_jac_to_host(self, d_jac_shard, host_jac, node_begin, node_end):
+        """``opty_hip_shard_jac_to_host``: the blocks of a node shard from
+        device memory into the dense page-locked host vector of the global
+        problem (only what changed after the first time)."""
+        _check(self._lib.opty_hip_shard_jac_to_host(
+            self._h, _ptr(d_jac_shard), _ptr(host_jac), node_begin, node_end))
 
     def eval_con_jac(self, free, con, jac, mem):
         _check(self._lib.opty_hip_eval_con_jac(

@@ -580,8 +580,18 @@ class ShardedCollocator(object):
                 (con_host is not None or jac_host is not None):
             tails = self.evaluate_instance(None, what)
         if jac_host is not None:
-            jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
-                jac, non_blocking=True)
+            if self._hip_mode and jac.is_contiguous() and \
+                    jac.numel() >= self._PACKED_MIN_VALUES:
+                # large shards: after the first copy only the entries that
+                # can change cross PCIe (opty_hip_shard_jac_to_host: packed
+                # on the device, scattered into the shared vector by this
+                # process's host threads); synchronous
+                self._use_stream()
+                self.collocator.hip.shard_jac_to_host(
+                    jac, jac_host.array, self.a, self.b)
+            else:
+                jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
+                    jac, non_blocking=True)
             if tails[1] is not None and self.nnz_inst:
                 jac_host.torch_view(self.P*ncn, self.nnz).copy_(
                     tails[1], non_blocking=True)
@@ -597,6 +607,10 @@ class ShardedCollocator(object):
         if tails[0] is not None:
             con_host.torch_view(self.M*ncn, self.num_constraints).copy_(
                 tails[0], non_blocking=True)
+
+    #: Jacobian values of a shard from which :meth:`to_host` moves only the
+    #: varying entries
+    _PACKED_MIN_VALUES = 1 << 20
 
     # -- host conveniences (NumPy in, NumPy out on every rank) -----------------------
     def _as_device(self, free_global):
