@@ -107,7 +107,9 @@ def assert_close(actual, desired, rtol=1e-10, scale=None, what='',
         st['entries'] += int(desired.size)
     bad = ~(err <= tol)          # NaNs are bad
     if bad.any():
-        k = int(np.argmax(np.where(np.isnan(err), np.inf, err/tol)))
+        with np.errstate(all='ignore'):
+            ratio = np.where(bad, np.where(tol > 0, err/tol, np.inf), -1.0)
+        k = int(np.argmax(np.where(np.isnan(ratio), np.inf, ratio)))
         raise AssertionError(
             '%s: %d/%d entries off; worst at %d: %r vs %r (err %.3g, tol '
             '%.3g)' % (what, bad.sum(), bad.size, k, actual.flat[k],
