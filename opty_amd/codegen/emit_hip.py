@@ -86,7 +86,13 @@ class EmitOptions(object):
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
-                 fused_groups=None, small_flush='flat'):
+                 fused_groups=None, small_flush='flat', con_split='work'):
+        # how the constraint rows are cut into waves: 'work' balances the
+        # waves' operation counts (_constraint_waves), 'count' gives every
+        # wave the same number of rows (the fallback when the balanced cut
+        # makes a kernel spill vector registers: hip_backend.spill_free)
+        assert con_split in ('work', 'count')
+        self.con_split = con_split
         # strips of opty_conjac when they differ from opty_jac's ``groups``
         # (None: as ``groups``, or automatic); what a measured launch plan
         # sets (opty_amd/launch_plan.py)
@@ -160,7 +166,8 @@ class EmitOptions(object):
                 (' fast_trig=1' if self.fast_trig else '') +
                 (' fused_groups=%d' % self.fused_groups
                  if self.fused_groups is not None else '') +
-                ('' if self.small_flush == 'flat' else ' small_flush=chunk'))
+                ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
+                ('' if self.con_split == 'work' else ' con_split=count'))
 
 
 def _lit(v):
@@ -1196,10 +1203,28 @@ def emit_module(prog, opts=None, node_blocks=None):
         return [list(range(a, min(a + rpw, prog.M)))
                 for a in range(0, prog.M, rpw)]
 
+    def by_count():
+        # equal row counts, as few waves as the register estimate allows
+        leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
+        parts = 1
+        while True:
+            sets = row_sets(-(-prog.M//parts))
+            worst = max(_max_live(prog.dag, [[prog.con_out[j]] for j in rs],
+                                  leaf) for rs in sets)
+            if worst <= 1.5*opts.max_live or len(sets) >= prog.M:
+                return sets
+            parts += 1
+
+    # opty_con's waves are balanced by work; the fused kernel's constraint
+    # waves as well unless that made it spill (``con_split='count'``: one
+    # register allocation serves all waves of a kernel, and next to Jacobian
+    # strips at the 512-VGPR limit the balanced cut of a 24-link system --
+    # 33 + 9 + 8 rows -- tipped it into scratch where 5 x 10 rows did not)
     if opts.con_rows_per_wave:
-        con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
+        alone_sets = con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
     else:
-        con_sets = _constraint_waves(prog, w, opts)
+        alone_sets = _constraint_waves(prog, w, opts)
+        con_sets = alone_sets if opts.con_split == 'work' else by_count()
     fused_jac = groups
     if opts.groups is None:
         live, auto = w.auto_groups()
@@ -1255,7 +1280,8 @@ def emit_module(prog, opts=None, node_blocks=None):
     nt_fused = opts.con_nt == 1 or (opts.con_nt is None and
                                     con_bytes > CON_CACHE_BYTES)
     for key, name, grp, cons, wpw, nt in (
-            ('con', 'opty_con', con_groups, con_sets, 1, nt_alone),
+            ('con', 'opty_con', [[(0, 0)]]*len(alone_sets), alone_sets, 1,
+             nt_alone),
             ('jac', 'opty_jac', list(groups) + [[(0, 0)]]*opts.pad,
              [[] for _ in range(len(groups) + opts.pad)], opts.waves, False),
             ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves,

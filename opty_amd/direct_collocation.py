@@ -526,14 +526,72 @@ class ConstraintCollocator(object):
 
     def generate_source(self):
         """HIP source of this problem's kernels and its launch metadata."""
+        return self._emit(self._printer_options())
+
+    def _launch_blocks(self):
         nodes = self._launch_nodes or self.num_collocation_nodes - 1
-        blocks = (int(nodes) + 63)//64
-        prog = self._build_program()
+        return (int(nodes) + 63)//64
+
+    def _printer_options(self):
         opts = self._emit_options
         if opts is None:
             from . import launch_plan
-            opts = launch_plan.lookup(prog, blocks) or EmitOptions()
-        return emit_module(prog, opts, node_blocks=blocks)
+            opts = launch_plan.lookup(self._build_program(),
+                                      self._launch_blocks()) or EmitOptions()
+        return opts
+
+    def _emit(self, opts):
+        return emit_module(self._build_program(), opts,
+                           node_blocks=self._launch_blocks())
+
+    def _build_code_object(self, opt_level=None):
+        """Emits and compiles this problem's module; returns ``(hsaco path,
+        meta)``.  Unless the caller fixed the printer options, a build whose
+        kernels spill VECTOR registers to scratch memory is not used (see
+        ``hip_backend.vgpr_spills``): the constraint rows are re-cut by
+        count, then the strips of the spilling kernels are made narrower,
+        until a build is spill-free."""
+        import copy
+        opts = self._printer_options()
+        source, meta = self._emit(opts)
+        hsaco = hb.compile_module(source, self.tmp_dir,
+                                  self.show_compile_output,
+                                  opt_level=opt_level)
+        if self._emit_options is not None:
+            return hsaco, meta
+        best = (hsaco, meta, hb.vgpr_spills(hsaco))
+        geo = meta['geometry']
+        steps = []
+        if geo['con_waves'] > 1 and opts.con_split == 'work':
+            steps.append(dict(con_split='count'))
+        steps += [dict(con_split='count', more=d) for d in (1, 2, 4)]
+        for step in steps:
+            if not best[2]:
+                break
+            trial = copy.copy(opts)
+            trial.con_split = step['con_split'] if geo['con_waves'] > 1 \
+                else opts.con_split
+            d = step.get('more', 0)
+            if d and not geo['line_mode']:
+                break
+            if d:
+                trial.groups = geo['jac'] + (d if 'opty_jac' in best[2]
+                                             else 0)
+                trial.fused_groups = geo['fused'] + (
+                    d if 'opty_conjac' in best[2] else 0)
+            logger.info('kernels %s spill vector registers: rebuilding with '
+                        '%s', sorted(best[2]), trial.key())
+            source, meta = self._emit(trial)
+            hsaco = hb.compile_module(source, self.tmp_dir,
+                                      self.show_compile_output,
+                                      opt_level=opt_level)
+            spills = hb.vgpr_spills(hsaco)
+            if sum(spills.values()) < sum(best[2].values()) or not spills:
+                best = (hsaco, meta, spills)
+        if best[2]:
+            logger.warning('kernels %s still spill vector registers to '
+                           'scratch memory', best[2])
+        return best[0], best[1]
 
     def tune_launch(self, **kwargs):
         """Times the neighbouring launch geometries of this problem on the
@@ -584,10 +642,8 @@ class ConstraintCollocator(object):
         device handle and uploads the node-invariant data."""
         if self._hip is not None:
             return self._hip
-        source, meta = self.generate_source()
         logger.info('Compiling the HIP constraint/Jacobian kernels.')
-        hsaco = hb.compile_module(source, self.tmp_dir,
-                                  self.show_compile_output)
+        hsaco, meta = self._build_code_object()
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
         self._install_tables(hip)
         self._kernel_meta = meta

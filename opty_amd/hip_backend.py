@@ -136,6 +136,54 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     return hsaco
 
 
+_RESOURCE_KEYS = ('.vgpr_count', '.agpr_count', '.sgpr_count',
+                  '.vgpr_spill_count', '.sgpr_spill_count',
+                  '.private_segment_fixed_size', '.group_segment_fixed_size')
+
+
+def kernel_resources(hsaco_path):
+    """``{kernel: {'.vgpr_count': ..., '.vgpr_spill_count': ...,
+    '.private_segment_fixed_size': ..., ...}}`` from the AMDGPU metadata note
+    of a code object built by :func:`compile_module`."""
+    import re
+    import tempfile
+    llvm = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.realpath(_hipcc()))), 'lib', 'llvm', 'bin')
+    if not os.path.isdir(llvm):
+        llvm = '/opt/rocm/lib/llvm/bin'
+    with tempfile.NamedTemporaryFile(suffix='.elf') as elf:
+        # `hipcc --genco` writes an offload bundle: take the gfx950 ELF out
+        subprocess.run([os.path.join(llvm, 'clang-offload-bundler'),
+                        '--unbundle', '--type=o', '--input=' + hsaco_path,
+                        '--targets=hipv4-amdgcn-amd-amdhsa--' + ARCH,
+                        '--output=' + elf.name], check=True,
+                       capture_output=True)
+        txt = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes',
+                              elf.name], capture_output=True,
+                             text=True).stdout
+    out = {}
+    for blk in txt.split('- .agpr_count')[1:]:
+        blk = '.agpr_count' + blk
+        name = re.search(r'\.name:\s+(\S+)', blk).group(1)
+        out[name] = {k: int(re.search(re.escape(k) + r':\s+(\d+)', blk)
+                            .group(1)) for k in _RESOURCE_KEYS}
+    return out
+
+
+def vgpr_spills(hsaco_path, kernels=('opty_con', 'opty_jac', 'opty_conjac')):
+    """``{kernel: spilled vector registers}`` for the kernels that spill
+    VECTOR registers to scratch memory.  The generated kernels are not allowed
+    to: at 512 VGPRs next to hundreds of SGPR spills hipcc 7.2 has produced
+    code objects whose results were wrong and differed from run to run (the
+    24-link stand-in with 19 strips: 32 spilled VGPRs, 100 B of scratch);
+    every such case seen so far spilled vector registers, none of the
+    spill-free builds misbehaved."""
+    res = kernel_resources(hsaco_path)
+    return {k: res[k]['.vgpr_spill_count'] for k in kernels
+            if k in res and (res[k]['.vgpr_spill_count'] > 0 or
+                             res[k]['.private_segment_fixed_size'] > 0)}
+
+
 class _Desc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int64)] + [
         (name, ctypes.c_int32) for name in (

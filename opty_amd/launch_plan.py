@@ -164,10 +164,18 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
     built = []
 
     def build(item):
+        # a candidate whose kernels spill vector registers is re-cut once
+        # (constraint rows by count); one that still spills does not compete
+        # for the kernel that spills (hip_backend.vgpr_spills)
         label, kw = item
-        source, meta = emit_module(prog, EmitOptions(**kw),
-                                   node_blocks=blocks)
-        return label, kw, meta, hb.compile_module(source, col.tmp_dir)
+        for attempt in (kw, dict(kw, con_split='count')):
+            source, meta = emit_module(prog, EmitOptions(**attempt),
+                                       node_blocks=blocks)
+            hsaco = hb.compile_module(source, col.tmp_dir)
+            spills = hb.vgpr_spills(hsaco)
+            if 'opty_conjac' not in spills:
+                break
+        return label, attempt, meta, hsaco, spills
 
     with ThreadPoolExecutor(max_workers) as pool:
         built = list(pool.map(build, cands))
@@ -183,7 +191,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
     con = torch.empty((prog.M, nodes), **f64)
     jac = torch.empty(nodes*prog.P, **f64)
     handles = []
-    for label, kw, meta, hsaco in built:
+    for label, kw, meta, hsaco, spills in built:
         h = hb.HipProblem(col._descriptor(meta), hsaco)
         col._install_tables(h)
         h.use_torch_stream()
@@ -202,6 +210,9 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
                     continue
                 if what == 'jac' and label.startswith('fused='):
                     continue
+                if {'fused': 'opty_conjac', 'jac': 'opty_jac'}[what] in \
+                        built[k][4]:
+                    continue            # spills vector registers
                 times[what][k].append(h.time_eval_shard(
                     sel[what], free, con, nodes, jac, a, b, iters))
     for h in handles:
@@ -209,7 +220,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
     best = {}
     measured = {'fused': {}, 'jac': {}}
     for what in ('fused', 'jac'):
-        for k, (label, kw, meta, _) in enumerate(built):
+        for k, (label, kw, meta, _, _) in enumerate(built):
             if not times[what][k]:
                 continue
             ms = float(np.median(times[what][k]))
@@ -237,7 +248,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
         options = dict(best['fused'][2])
         shape = lambda kw: (kw.get('chunk', 32), kw.get('waves'))
         same = [(float(np.median(times['jac'][k])), kw)
-                for k, (label, kw, _, _) in enumerate(built)
+                for k, (label, kw, _, _, _) in enumerate(built)
                 if times['jac'][k] and shape(kw) == shape(options)]
         if same:
             options['groups'] = min(same, key=lambda t: t[0])[1]['groups']

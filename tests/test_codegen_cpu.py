@@ -614,3 +614,24 @@ def test_varying_entries_against_the_reference_values(name):
             (dag.args[i][0] == 'h' and prog.h[0] != 'fixed'))}
         for e in static:
             assert not tail & set(dag.reachable([prog.jac_out[e]]))
+
+
+@pytest.mark.parametrize('name,launch_nodes', [
+    ('config3_10link_small', None), ('config3_10link_small', 12500),
+    ('config5_standin_24link_small', None),
+    ('config5_standin_24link_small', 6250),
+    ('config5_gaitlike_24link_small', 6250), ('elementary_mid_small', None)])
+def test_built_kernels_do_not_spill_vector_registers(name, launch_nodes):
+    """The code object a collocator uses has no kernel that spills VECTOR
+    registers to scratch memory (``ConstraintCollocator._build_code_object``
+    re-cuts until that holds): builds of the 24-link systems that did spill
+    returned wrong, run-to-run different values on MI355X
+    (``hip_backend.vgpr_spills``)."""
+    col = ConstraintCollocator(launch_nodes=launch_nodes,
+                               **problems.build(name))
+    hsaco, meta = col._build_code_object()
+    assert hb.vgpr_spills(hsaco) == {}
+    res = hb.kernel_resources(hsaco)
+    for kern in ('opty_con', 'opty_jac', 'opty_conjac'):
+        assert res[kern]['.private_segment_fixed_size'] == 0
+        assert res[kern]['.vgpr_count'] <= 512

@@ -593,37 +593,42 @@ def test_callbacks_over_rccl_single_rank(tmp_path):
 def test_shard_to_host_moves_only_what_changed():
     """``ShardedCollocator.to_host`` on a large shard: the first copy moves the
     whole slice, later ones only the varying entries
-    (``opty_hip_shard_jac_to_host``); the shared host vector always equals the
-    dense copy of a whole-problem evaluation in this rank's slice -- also
-    after a known-parameter change -- and nothing outside the slice is
-    touched."""
+    (``opty_hip_shard_jac_to_host``); this rank's slice of the shared host
+    vector always equals the shard's values in device memory bit for bit --
+    also after a known-parameter change and for an in-place shard -- and
+    nothing outside the slice is touched."""
     import torch
-    import opty_amd
-    from opty_amd import hip_backend as hb
     from opty_amd.sharded import ShardedCollocator, SharedHostVector
     factory, fkw = problems.CONFIGS['config3_10link']
     kw = factory(**dict(fkw, num_nodes=30001))
     sh = ShardedCollocator(rank=1, world_size=3, **kw)
     assert sh.jac_local.numel() >= sh._PACKED_MIN_VALUES
-    whole = opty_amd.ConstraintCollocator(**kw)
     jac_host = SharedHostVector('opty_t_pack', sh.nnz, 0,
                                 pin=(sh.a*sh.P, sh.b*sh.P))
     jac_host.array[:] = -7.0
-    dense = hb.pinned_empty(whole.hip.nnz)
     lo, hi = sh.a*sh.P, sh.b*sh.P
+    seen = []
     for k, seed in enumerate((1, 2, 3, 4)):
         if k == 3:
             key = list(kw['known_parameter_map'])[-1]
-            for m in (kw['known_parameter_map'],
-                      whole.known_parameter_map):
-                m[key] = 2.5
-        free = problems.make_free(whole.num_free, seed=seed)
-        sh.evaluate(torch.from_numpy(free).cuda(), in_place=(k == 2))
+            kw['known_parameter_map'][key] = 2.5
+        free = problems.make_free(sh.collocator.num_free, seed=seed)
+        _, jac = sh.evaluate(torch.from_numpy(free).cuda(),
+                             in_place=(k == 2))
         sh.to_host(None, jac_host)
         torch.cuda.synchronize()
-        whole.hip.eval_jac(free, dense, hb.HOST) if k < 3 else \
-            np.copyto(dense, whole.generate_jacobian_function()(free))
-        np.testing.assert_array_equal(jac_host.array[lo:hi], dense[lo:hi])
+        want = jac.cpu().numpy()
+        np.testing.assert_array_equal(jac_host.array[lo:hi], want)
         assert (jac_host.array[:lo] == -7.0).all()
         assert (jac_host.array[hi:] == -7.0).all()
+        seen.append(want.copy())
+    assert not np.array_equal(seen[0], seen[1])
+    # the parameter change moved node-invariant entries too
+    P = sh.P
+    from opty_amd.codegen.program import varying_entries
+    var = set(varying_entries(sh.collocator._build_program()))
+    static = [e for e in range(P) if e not in var]
+    blk2, blk3 = seen[2].reshape(-1, P), seen[3].reshape(-1, P)
+    assert (blk2[:, static] == blk2[0, static]).all()
+    assert not np.array_equal(blk2[0, static], blk3[0, static])
     jac_host.close()
