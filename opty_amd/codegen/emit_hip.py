@@ -1100,7 +1100,7 @@ def _node_weight(dag, i):
     return _OP_WEIGHT.get(dag.op[i], 1)
 
 
-def _constraint_waves(prog, w, opts):
+def _constraint_waves(prog, w, opts, scale=1.0):
     """Splits the M constraint rows over as few waves as the register budget
     allows, balanced by WORK, not by count.
 
@@ -1136,7 +1136,9 @@ def _constraint_waves(prog, w, opts):
                 total += _node_weight(dag, i)
                 stack.extend(dag.operands(i))
             cost[a][b + 1] = total + 2*(b + 1 - a)       # + the row's store
-    budget = 1.5*opts.max_live
+    # (``scale``: 0.5 when the kernels are capped at 256 VGPRs, two waves
+    # per SIMD)
+    budget = 1.5*opts.max_live*scale
     best = None
     for k in range(1, M + 1):
         # linear partition: minimise the largest range cost
@@ -1223,7 +1225,8 @@ def emit_module(prog, opts=None, node_blocks=None):
     if opts.con_rows_per_wave:
         alone_sets = con_sets = row_sets(max(1, int(opts.con_rows_per_wave)))
     else:
-        alone_sets = _constraint_waves(prog, w, opts)
+        alone_sets = _constraint_waves(
+            prog, w, opts, 0.5 if opts.occupancy == 2 else 1.0)
         con_sets = alone_sets if opts.con_split == 'work' else by_count()
     fused_jac = groups
     if opts.groups is None:
@@ -1234,13 +1237,19 @@ def emit_module(prog, opts=None, node_blocks=None):
             else auto
         dual = None
         if node_blocks and int(node_blocks)*(fused + len(con_sets)) > \
-                RESIDENT_WAVES:
-            dual = _dual_occupancy_cut(prog, w, opts, live, len(con_sets),
+                RESIDENT_WAVES and not opts.con_rows_per_wave:
+            # at two waves per SIMD every wave has half the registers: the
+            # constraint rows are cut for that budget (one wave for the 22
+            # rows of the 10-link system needs 258 VGPRs, two spills under
+            # the 256 cap)
+            dual_sets = _constraint_waves(prog, w, opts, 0.5)
+            dual = _dual_occupancy_cut(prog, w, opts, live, len(dual_sets),
                                        int(node_blocks))
         if dual is not None:
             opts, fused = dual
             w = _ModuleWriter(prog, opts)
             groups = w.group_ranges(fused)
+            alone_sets = con_sets = dual_sets
         elif node_blocks:
             fit = _fit_one_round(auto, len(con_sets), int(node_blocks), live)
             if fit != auto:

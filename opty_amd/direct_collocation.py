@@ -561,33 +561,46 @@ class ConstraintCollocator(object):
             return hsaco, meta
         best = (hsaco, meta, hb.vgpr_spills(hsaco))
         geo = meta['geometry']
+        # where spills appear is erratic in the cut (24-link stand-in, fused
+        # strips 18 ... 28: only 20, 25 and 28 are spill-free), so the
+        # narrower cuts are tried a few at a time, in parallel (hipcc is a
+        # subprocess), and the first spill-free one in this order wins
         steps = []
         if geo['con_waves'] > 1 and opts.con_split == 'work':
-            steps.append(dict(con_split='count'))
-        steps += [dict(con_split='count', more=d) for d in (1, 2, 4)]
-        for step in steps:
-            if not best[2]:
-                break
+            steps.append(0)
+        if geo['line_mode']:
+            steps += [1, 2, 3, 4, 5, 6, 8, 10, 12]
+
+        def attempt(d):
             trial = copy.copy(opts)
-            trial.con_split = step['con_split'] if geo['con_waves'] > 1 \
-                else opts.con_split
-            d = step.get('more', 0)
-            if d and not geo['line_mode']:
-                break
+            if geo['con_waves'] > 1:
+                trial.con_split = 'count'
             if d:
                 trial.groups = geo['jac'] + (d if 'opty_jac' in best[2]
                                              else 0)
                 trial.fused_groups = geo['fused'] + (
                     d if 'opty_conjac' in best[2] else 0)
-            logger.info('kernels %s spill vector registers: rebuilding with '
-                        '%s', sorted(best[2]), trial.key())
             source, meta = self._emit(trial)
             hsaco = hb.compile_module(source, self.tmp_dir,
                                       self.show_compile_output,
                                       opt_level=opt_level)
-            spills = hb.vgpr_spills(hsaco)
-            if sum(spills.values()) < sum(best[2].values()) or not spills:
-                best = (hsaco, meta, spills)
+            return hsaco, meta, hb.vgpr_spills(hsaco)
+
+        from concurrent.futures import ThreadPoolExecutor
+        while best[2] and steps:
+            batch, steps = steps[:4], steps[4:]
+            logger.info('kernels %s spill vector registers: rebuilding with '
+                        'narrower cuts %s', sorted(best[2]), batch)
+            with ThreadPoolExecutor(len(batch)) as pool:
+                results = list(pool.map(attempt, batch))
+            clean = [r for r in results if not r[2]]
+            if clean:
+                best = clean[0]
+            else:
+                least = min(results, key=lambda r: sum(r[2].values()))
+                if sum(least[2].values()) < sum(best[2].values()):
+                    best = (least[0], least[1], best[2])   # keep the list
+                    best = least
         if best[2]:
             logger.warning('kernels %s still spill vector registers to '
                            'scratch memory', best[2])
