@@ -505,10 +505,12 @@ def test_strip_count_rules():
     assert waves(None) == (10, 10, 1)           # 10 strips; 9 strips + 1 con
     assert waves(1563) == (10, 10, 1)           # N = 100 000
     assert waves(391) == (10, 10, 1)            # 4 shards: several rounds
-    # 8 shards (12 500 nodes): two waves per SIMD, 7 strips + 1 constraint
-    # wave = 2 workgroups of 4 waves per block, all 1568 waves resident
+    # 8 shards (12 500 nodes): two waves per SIMD, 6 strips + 2 constraint
+    # waves (the 22 rows cut for half the register file: one wave needs 258
+    # VGPRs, two spills under the 256 cap) = 2 workgroups of 4 waves per
+    # block, all 1568 waves resident
     jac, fused, wpw = waves(196)
-    assert (jac, fused, wpw) == (7, 8, 4)
+    assert (jac, fused, wpw) == (6, 8, 4)
     assert 196*fused <= 2*RESIDENT_WAVES
     src = emit_module(prog, EmitOptions(), node_blocks=196)[0]
     assert 'amdgpu_waves_per_eu(2, 2)' in src and 'chunk=16' in src
