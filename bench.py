@@ -41,10 +41,11 @@ import os
 import sys
 import time
 
-# the CPU baseline's OpenMP team is pinned; libgomp reads
-# these when it is loaded, i.e. before `import torch`
-os.environ.setdefault('OMP_PROC_BIND', 'close')
-os.environ.setdefault('OMP_PLACES', 'cores')
+# The CPU baseline's OpenMP team is pinned.  libgomp reads
+# OMP_PROC_BIND / OMP_PLACES when it is loaded and then binds the thread that
+# loaded it -- which would also pin the GPU process's host threads -- so the
+# baseline runs in a child process of its own (`--cpu-baseline-only`).
+CPU_BASELINE_ENV = {'OMP_PROC_BIND': 'close', 'OMP_PLACES': 'cores'}
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -89,7 +90,7 @@ def host_cpu():
                 numa_nodes=numa)
 
 
-def cpu_baseline(kw, budget_s=24.0):
+def _cpu_baseline_impl(kw, budget_s=24.0):
     """The oracle's C/OpenMP restatement of the reference's generated code
     (validated against the real reference's wall time on the same cores by
     ``tests/golden/_gen/time_reference.py``), timed on this box's host cores
@@ -179,6 +180,20 @@ def cpu_baseline(kw, budget_s=24.0):
                    os.environ.get('OMP_PLACES'), cpu['model'],
                    cpu['sockets'], cpu['physical_cores'],
                    cpu['logical_cpus'], cpu['numa_nodes'], detail))
+
+
+def cpu_baseline(nodes):
+    """Runs :func:`_cpu_baseline_impl` in a child process with the OpenMP
+    binding environment and returns its dictionary."""
+    import subprocess
+    env = dict(os.environ, **CPU_BASELINE_ENV)
+    proc = subprocess.run([sys.executable, os.path.abspath(__file__),
+                           '--cpu-baseline-only', '--nodes', str(nodes)],
+                          capture_output=True, text=True, env=env, cwd=REPO)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    if proc.returncode != 0 or not lines:
+        return {'error': proc.stderr[-2000:]}
+    return json.loads(lines[-1])
 
 
 def lookup_traffic(kernel_sha):
@@ -424,10 +439,20 @@ def main():
                     help='untimed clock-ramp phase before the warm-up steps '
                          '(wall milliseconds of the same step; 0 disables)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='(internal) time the CPU baseline in this process '
+                         'and print its JSON')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary figures (serial pair, host path, '
                          'other configs, re-assembly variants)')
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:
+        from examples import problems
+        factory, fkw = problems.CONFIGS[WORKLOAD]
+        print(json.dumps(_cpu_baseline_impl(
+            factory(**dict(fkw, num_nodes=args.nodes)))))
+        return
 
     import torch
     import torch.distributed as dist
@@ -762,7 +787,7 @@ def main():
         out['config'].update(extras)
         out['config']['verify'] = verify
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(kw)
+            out['cpu_baseline'] = cpu_baseline(args.nodes)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
