@@ -257,14 +257,46 @@ private:
     }
 
     void work(int t, int T, unsigned long long seen) {
-        // A host application that binds its OpenMP team (OMP_PROC_BIND) pins
-        // the thread that loads this library to one core, and new threads
-        // inherit the mask: sixteen workers on one core turn 5.9 ms into 40.
-        // The workers may run wherever the process is allowed to.
-        cpu_set_t all;
-        CPU_ZERO(&all);
-        for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &all);
-        (void)sched_setaffinity(0, sizeof all, &all);
+        // New threads inherit the creating thread's CPU mask.  Usually that is
+        // what is wanted (a launcher's numactl / cpuset keeps the workers next
+        // to the page-locked vectors: 5.8 ms; spread over both sockets: 8.5).
+        // But a host application that binds its OpenMP team (OMP_PROC_BIND)
+        // pins the thread that loads this library to ONE core, and sixteen
+        // workers on one core turn 5.9 ms into 40: a mask with fewer CPUs
+        // than workers is widened to the NUMA node the thread is on.
+        cpu_set_t mask;
+        if (sched_getaffinity(0, sizeof mask, &mask) == 0 &&
+            CPU_COUNT(&mask) < T) {
+            cpu_set_t wide;
+            CPU_ZERO(&wide);
+            char path[96], buf[4096];
+            int node = 0;
+            const int cpu = sched_getcpu();
+            for (int n = 0; n < 64 && cpu >= 0; ++n) {
+                snprintf(path, sizeof path,
+                         "/sys/devices/system/node/node%d/cpu%d", n, cpu);
+                if (access(path, F_OK) == 0) { node = n; break; }
+            }
+            snprintf(path, sizeof path,
+                     "/sys/devices/system/node/node%d/cpulist", node);
+            FILE *f = fopen(path, "r");
+            if (f && fgets(buf, sizeof buf, f)) {
+                char *save = nullptr;
+                for (char *tok = strtok_r(buf, ",\n", &save); tok;
+                     tok = strtok_r(nullptr, ",\n", &save)) {
+                    int lo = 0, hi = 0;
+                    const int got = sscanf(tok, "%d-%d", &lo, &hi);
+                    if (got == 1) hi = lo;
+                    for (int c = lo; got >= 1 && c <= hi && c < CPU_SETSIZE;
+                         ++c)
+                        CPU_SET(c, &wide);
+                }
+            }
+            if (f) fclose(f);
+            if (CPU_COUNT(&wide) < T)
+                for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &wide);
+            (void)sched_setaffinity(0, sizeof wide, &wide);
+        }
         for (;;) {
             {
                 std::unique_lock<std::mutex> lk(m_);
