@@ -91,14 +91,16 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     # -O2, not -O3: identical kernel times (10-link and 24-link systems).  In
     # round 1 a hipcc 7.2 -O3 build of one generated kernel (24-link
     # pendulum, row-sorted layout) returned 1e16 in two entries of equation 47
-    # at every node while -O1/-O2/-Os agreed with the reference to 1e-13.
-    # Round 2 could not reproduce it -- neither with the whole module of that
-    # commit nor with the reduced kernel kept in tools/o3_repro/ (-O2 and -O3
-    # results are bit-identical) -- so the cause is unknown; -O2 stays the
-    # default because it costs nothing, and
-    # tests/test_hip_parity.py::test_optimisation_levels_agree cross-checks
-    # -O1 against the default on every run.  OPTY_HIPCC_OPT / OPTY_HIPCC_FLAGS
-    # override for experiments.
+    # at every node while -O1/-O2/-Os agreed with the reference; round 2 could
+    # not reproduce it.  Round 3 met the same kind of failure twice more --
+    # wrong, run-to-run different values confined to one strip of a 24-link
+    # kernel -- and every such build spilled VECTOR registers (512 VGPRs next
+    # to hundreds of SGPR spills); no spill-free build has misbehaved.  That is
+    # what is enforced now (vgpr_spills below; ConstraintCollocator.
+    # _build_code_object never uses a spilling build); -O2 stays the default
+    # because it costs nothing, and tests/test_hip_parity.py::
+    # test_optimisation_levels_agree cross-checks -O1 against the default on
+    # every run.  OPTY_HIPCC_OPT / OPTY_HIPCC_FLAGS override for experiments.
     flags = ['--offload-arch=' + ARCH,
              opt_level or os.environ.get('OPTY_HIPCC_OPT', '-O2'),
              '-std=c++17'] + \
