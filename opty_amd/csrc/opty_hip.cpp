@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -213,6 +214,36 @@ public:
 
     int threads() const { return (int)workers_.size(); }
 
+    // CPUs of NUMA node `node` (the one the GPU of this process hangs off);
+    // restarts the workers there.  node < 0: unknown, nothing changes.
+    void set_numa_node(int node) {
+        if (node < 0 || node == node_) return;
+        char path[96], buf[4096];
+        snprintf(path, sizeof path,
+                 "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = fopen(path, "r");
+        if (!f) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (fgets(buf, sizeof buf, f)) {
+            char *save = nullptr;
+            for (char *tok = strtok_r(buf, ",\n", &save); tok;
+                 tok = strtok_r(nullptr, ",\n", &save)) {
+                int lo = 0, hi = 0;
+                const int got = sscanf(tok, "%d-%d", &lo, &hi);
+                if (got == 1) hi = lo;
+                for (int c = lo; got >= 1 && c <= hi && c < CPU_SETSIZE; ++c)
+                    CPU_SET(c, &set);
+            }
+        }
+        fclose(f);
+        if (CPU_COUNT(&set) == 0) return;
+        node_ = node;
+        cpus_ = set;
+        have_cpus_ = true;
+        resize(threads());
+    }
+
     void resize(int n) {
         stop();
         n = std::max(1, std::min(n, 256));
@@ -257,44 +288,21 @@ private:
     }
 
     void work(int t, int T, unsigned long long seen) {
-        // New threads inherit the creating thread's CPU mask.  Usually that is
-        // what is wanted (a launcher's numactl / cpuset keeps the workers next
-        // to the page-locked vectors: 5.8 ms; spread over both sockets: 8.5).
-        // But a host application that binds its OpenMP team (OMP_PROC_BIND)
-        // pins the thread that loads this library to ONE core, and sixteen
-        // workers on one core turn 5.9 ms into 40: a mask with fewer CPUs
-        // than workers is widened to the NUMA node the thread is on.
+        // The page-locked vectors the workers read and write come from
+        // hipHostMalloc, i.e. from the NUMA node next to the GPU: the workers
+        // run on that node's cores (set_numa_node).  Without that information
+        // they inherit the creating thread's mask -- unless it is narrower
+        // than the pool: a host application that binds its OpenMP team
+        // (OMP_PROC_BIND) pins the thread that loads this library to ONE
+        // core, and sixteen workers on one core turn 5.9 ms into 40.
         cpu_set_t mask;
-        if (sched_getaffinity(0, sizeof mask, &mask) == 0 &&
-            CPU_COUNT(&mask) < T) {
+        if (have_cpus_) {
+            (void)sched_setaffinity(0, sizeof cpus_, &cpus_);
+        } else if (sched_getaffinity(0, sizeof mask, &mask) == 0 &&
+                   CPU_COUNT(&mask) < T) {
             cpu_set_t wide;
             CPU_ZERO(&wide);
-            char path[96], buf[4096];
-            int node = 0;
-            const int cpu = sched_getcpu();
-            for (int n = 0; n < 64 && cpu >= 0; ++n) {
-                snprintf(path, sizeof path,
-                         "/sys/devices/system/node/node%d/cpu%d", n, cpu);
-                if (access(path, F_OK) == 0) { node = n; break; }
-            }
-            snprintf(path, sizeof path,
-                     "/sys/devices/system/node/node%d/cpulist", node);
-            FILE *f = fopen(path, "r");
-            if (f && fgets(buf, sizeof buf, f)) {
-                char *save = nullptr;
-                for (char *tok = strtok_r(buf, ",\n", &save); tok;
-                     tok = strtok_r(nullptr, ",\n", &save)) {
-                    int lo = 0, hi = 0;
-                    const int got = sscanf(tok, "%d-%d", &lo, &hi);
-                    if (got == 1) hi = lo;
-                    for (int c = lo; got >= 1 && c <= hi && c < CPU_SETSIZE;
-                         ++c)
-                        CPU_SET(c, &wide);
-                }
-            }
-            if (f) fclose(f);
-            if (CPU_COUNT(&wide) < T)
-                for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &wide);
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &wide);
             (void)sched_setaffinity(0, sizeof wide, &wide);
         }
         for (;;) {
@@ -327,6 +335,9 @@ private:
     }
 
     pid_t pid_;
+    int node_ = -1;
+    bool have_cpus_ = false;
+    cpu_set_t cpus_;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::condition_variable cv_;
@@ -1474,6 +1485,38 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
     return 0;
 }
 
+// NUMA node of a device (sysfs, through its PCI address); -1 when unknown or
+// when OPTY_HIP_HOST_NUMA=off.
+static int device_numa_node(int device) {
+    static int cached[64];
+    static bool known[64];
+    if (device < 0 || device >= 64) return -1;
+    if (known[device]) return cached[device];
+    int node = -1;
+    const char *env = getenv("OPTY_HIP_HOST_NUMA");
+    if (env && strcmp(env, "off") == 0) {
+        node = -1;
+    } else if (env && *env) {
+        node = atoi(env);
+    } else {
+        char bus[64] = {0}, path[160];
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
+            for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node",
+                     bus);
+            if (FILE *f = fopen(path, "r")) {
+                if (fscanf(f, "%d", &node) != 1) node = -1;
+                fclose(f);
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    cached[device] = node;
+    known[device] = true;
+    return node;
+}
+
 // Moves the dense blocks of `count` nodes from device memory (d_blocks) into
 // host memory (h_blocks, page-locked): all of it (`full`), or only the varying
 // entries -- packed on the device, copied in chunks, scattered by the host
@@ -1529,6 +1572,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
     }
     ScatterPool &pool = ScatterPool::instance();
+    pool.set_numa_node(device_numa_node(p->d.device));
     ScatterPool::Job job;
     job.packed = p->h_packed;
     job.dense = h_blocks;
