@@ -192,9 +192,9 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
 /* Host threads of the scatter pool (per process; 0 = the default:
  * OPTY_HIP_HOST_THREADS, or min(16, hardware threads / 2 / LOCAL_WORLD_SIZE)
  * -- the ranks of a node share its cores).  The workers run on the cores of
- * the NUMA node the handle's GPU hangs off (where hipHostMalloc puts the
- * page-locked vectors); OPTY_HIP_HOST_NUMA=<node> overrides, =off leaves
- * them where the creating thread may run. */
+ * the NUMA node that holds the caller's dense vector (get_mempolicy);
+ * OPTY_HIP_HOST_NUMA=<node> overrides, =off leaves them where the creating
+ * thread may run. */
 int opty_hip_set_host_threads(int32_t count);
 int opty_hip_host_threads(void);
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <sched.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -214,8 +215,9 @@ public:
 
     int threads() const { return (int)workers_.size(); }
 
-    // CPUs of NUMA node `node` (the one the GPU of this process hangs off);
-    // restarts the workers there.  node < 0: unknown, nothing changes.
+    // CPUs of NUMA node `node` (the one that holds the vector being
+    // assembled); restarts the workers there.  node < 0: unknown, nothing
+    // changes.
     void set_numa_node(int node) {
         if (node < 0 || node == node_) return;
         char path[96], buf[4096];
@@ -288,9 +290,8 @@ private:
     }
 
     void work(int t, int T, unsigned long long seen) {
-        // The page-locked vectors the workers read and write come from
-        // hipHostMalloc, i.e. from the NUMA node next to the GPU: the workers
-        // run on that node's cores (set_numa_node).  Without that information
+        // The workers run on the cores of the NUMA node that holds the
+        // caller's dense vector (set_numa_node).  Without that information
         // they inherit the creating thread's mask -- unless it is narrower
         // than the pool: a host application that binds its OpenMP team
         // (OMP_PROC_BIND) pins the thread that loads this library to ONE
@@ -1485,35 +1486,20 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
     return 0;
 }
 
-// NUMA node of a device (sysfs, through its PCI address); -1 when unknown or
-// when OPTY_HIP_HOST_NUMA=off.
-static int device_numa_node(int device) {
-    static int cached[64];
-    static bool known[64];
-    if (device < 0 || device >= 64) return -1;
-    if (known[device]) return cached[device];
-    int node = -1;
+// NUMA node that holds the page of `addr` (get_mempolicy; -1 when unknown).
+// The scatter workers run where the caller's dense vector lives: page-locked
+// memory sits on the node of the thread that allocated it, which need not be
+// the GPU's (measured on a 2-socket box, 792 MB vector on node 1: workers on
+// node 1 6.4 ms, wherever the scheduler puts them 8.0, on node 0 12.6).
+// OPTY_HIP_HOST_NUMA=<node> overrides, =off leaves the workers unplaced.
+static int host_numa_node(const void *addr) {
     const char *env = getenv("OPTY_HIP_HOST_NUMA");
-    if (env && strcmp(env, "off") == 0) {
-        node = -1;
-    } else if (env && *env) {
-        node = atoi(env);
-    } else {
-        char bus[64] = {0}, path[160];
-        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) {
-            for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
-            snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node",
-                     bus);
-            if (FILE *f = fopen(path, "r")) {
-                if (fscanf(f, "%d", &node) != 1) node = -1;
-                fclose(f);
-            }
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    cached[device] = node;
-    known[device] = true;
+    if (env && strcmp(env, "off") == 0) return -1;
+    if (env && *env) return atoi(env);
+    int node = -1;
+    // MPOL_F_NODE | MPOL_F_ADDR
+    if (syscall(SYS_get_mempolicy, &node, nullptr, 0UL, addr, 1UL | 2UL) != 0)
+        return -1;
     return node;
 }
 
@@ -1572,7 +1558,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
     }
     ScatterPool &pool = ScatterPool::instance();
-    pool.set_numa_node(device_numa_node(p->d.device));
+    pool.set_numa_node(host_numa_node(h_blocks));
     ScatterPool::Job job;
     job.packed = p->h_packed;
     job.dense = h_blocks;
