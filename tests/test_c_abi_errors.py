@@ -164,3 +164,78 @@ def test_host_register_misuse_fails():
     hb.host_register(a)
     hb.host_unregister(a)
     assert lib.opty_hip_host_unregister(None) == 0
+
+
+def test_round3_entry_points_reject_misuse():
+    """``opty_hip_eval_instance``, ``opty_hip_set_varying_entries``,
+    ``opty_hip_eval_jac_persistent``, ``opty_hip_shard_jac_to_host``."""
+    import torch
+    col, hip, hb = _fresh('config2_pendulum_small')
+    P = hip.desc['P']
+    with pytest.raises(hb.HipBackendError, match='ascend'):
+        hip.set_varying_entries([3, 2])
+    with pytest.raises(hb.HipBackendError, match='ascend'):
+        hip.set_varying_entries([0, P])
+    with pytest.raises(hb.HipBackendError, match='ascend'):
+        hip.set_varying_entries([1, 1])
+    hip.set_varying_entries([])                     # a block of constants
+    hip.set_varying_entries([0, 5])
+    free = problems.make_free(col.num_free)
+    jac = hb.pinned_empty(hip.nnz)
+    with pytest.raises(hb.HipBackendError, match='parameter'):
+        hip.eval_jac_persistent(free, jac)          # not configured yet
+    with pytest.raises(hb.HipBackendError, match='null'):
+        hip.eval_jac_persistent(None, jac)
+    dfree = torch.from_numpy(free).cuda()
+    tail = torch.empty(4, dtype=torch.float64, device='cuda')
+    with pytest.raises(hb.HipBackendError, match='parameter'):
+        hip.eval_instance(dfree, tail, None)
+    with pytest.raises(hb.HipBackendError, match='null'):
+        hip.eval_instance(None, tail, None)
+    djac = torch.empty(10*P, dtype=torch.float64, device='cuda')
+    ncn = col.num_collocation_nodes - 1
+    with pytest.raises(hb.HipBackendError, match='outside'):
+        hip.shard_jac_to_host(djac, jac, ncn - 5, ncn + 5)
+    with pytest.raises(hb.HipBackendError, match='null'):
+        hip.shard_jac_to_host(djac, None, 0, 10)
+    hip.close()
+    # problems without instance constraints: eval_instance is a no-op
+    col2, hip2, _ = _fresh('config1_vyasarayani')
+    hip2.eval_instance(torch.zeros(col2.num_free, dtype=torch.float64,
+                                   device='cuda'), None, None)
+    hip2.close()
+    # the row-sorted layout has no varying-entry table
+    col3, hip3, _ = _fresh('msd_be_small', jacobian_layout='csr')
+    with pytest.raises(hb.HipBackendError, match='node-major'):
+        hip3.set_varying_entries([0])
+    hip3.close()
+    with pytest.raises(hb.HipBackendError):
+        hb.set_host_threads(-1)
+
+
+def test_tune_launch_records_a_plan_and_keeps_the_results(tmp_path,
+                                                          monkeypatch):
+    """``ConstraintCollocator.tune_launch``: the candidate geometries of a
+    small problem are built, timed and a well-formed plan entry recorded; the
+    collocator rebuilt from the plan returns the same values."""
+    import json
+    import opty_amd
+    from opty_amd import launch_plan as lp
+    path = tmp_path/'plans.json'
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(path))
+    factory, fkw = problems.CONFIGS['pend3_link_midpoint_small']
+    kw = factory(**dict(fkw, num_nodes=20001))
+    col = opty_amd.ConstraintCollocator(**kw)
+    free = problems.make_free(col.num_free, seed=5)
+    before = col.generate_jacobian_function()(free).copy()
+    entry = col.tune_launch(iters=10, rounds=2)
+    plans = json.loads(path.read_text())
+    key = lp.key_of(col._build_program(), (20000 + 63)//64)
+    assert plans[key]['options'] == entry['options']
+    assert set(entry['measured_ms']) == {'fused', 'jac'}
+    assert all(v > 0 for v in entry['measured_ms']['fused'].values())
+    assert str(entry['seed']['fused']) in entry['measured_ms']['fused']
+    opts = lp.lookup(col._build_program(), (20000 + 63)//64)
+    assert opts is not None
+    after = col.generate_jacobian_function()(free)
+    np.testing.assert_allclose(after, before, rtol=1e-12, atol=1e-9)
