@@ -197,6 +197,8 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
  * thread may run. */
 int opty_hip_set_host_threads(int32_t count);
 int opty_hip_host_threads(void);
+/* NUMA node that holds the first page of a host allocation (-1: unknown). */
+int opty_hip_host_numa_node(const void *ptr);
 
 /* jacobian_indices(): writes nnz int64 rows and cols -- the closed form of
  * ConstraintCollocator.jacobian_indices (opty/direct_collocation.py:2450-2690,

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -214,6 +215,7 @@ public:
     }
 
     int threads() const { return (int)workers_.size(); }
+    int numa_node() const { return node_; }
 
     // CPUs of NUMA node `node` (the one that holds the vector being
     // assembled); restarts the workers there.  node < 0: unknown, nothing
@@ -1569,17 +1571,34 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     job.chunks = chunks;
     job.P = P;
     job.nodes = count;
+    // OPTY_HIP_TRACE=1: where the time of one call goes (stderr)
+    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t0 = trace ? now() : 0.0;
     pool.start(job);
     int rc = 0;
+    double t_first = 0.0;
     for (int c = 0; c < chunks; ++c) {
         hipError_t e = hipEventSynchronize(p->chunk_events[c]);
         if (e != hipSuccess && rc == 0) {
             (void)hipGetLastError();
             rc = fail("hipEventSynchronize failed: %s", hipGetErrorString(e));
         }
+        if (trace && c == 0) t_first = now();
         pool.ready(c + 1);      // also after a failure: the workers must end
     }
+    const double t_dma = trace ? now() : 0.0;
     pool.wait();
+    if (trace)
+        fprintf(stderr, "opty_hip: %lld nodes x %d entries in %d chunks: "
+                "first chunk landed +%.2f ms, last +%.2f ms, scatter done "
+                "+%.2f ms; %d threads on NUMA node %d (vector on node %d), "
+                "caller on cpu %d\n", count, V, chunks, t_first - t0,
+                t_dma - t0, now() - t0, pool.threads(), pool.numa_node(),
+                host_numa_node(h_blocks), sched_getcpu());
     return rc;
 }
 
@@ -1648,6 +1667,14 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
     p->shard_end = node_end;
     p->shard_valid = true;
     return 0;
+}
+
+int opty_hip_host_numa_node(const void *ptr) {
+    if (!ptr) return -1;
+    int node = -1;
+    if (syscall(SYS_get_mempolicy, &node, nullptr, 0UL, ptr, 1UL | 2UL) != 0)
+        return -1;
+    return node;
 }
 
 int opty_hip_host_register(void *ptr, size_t bytes) {

@@ -251,6 +251,7 @@ _SIGNATURES = {
         _P, _P, _P, ctypes.c_int64, ctypes.c_int64]),
     'opty_hip_set_host_threads': (ctypes.c_int, [ctypes.c_int32]),
     'opty_hip_host_threads': (ctypes.c_int, []),
+    'opty_hip_host_numa_node': (ctypes.c_int, [_P]),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
@@ -364,6 +365,11 @@ def set_host_threads(count=0):
 
 def host_threads():
     return load_library().opty_hip_host_threads()
+
+
+def host_numa_node(array):
+    """NUMA node that holds the first page of a NumPy array (-1: unknown)."""
+    return load_library().opty_hip_host_numa_node(array.ctypes.data)
 
 
 def host_register(array):
