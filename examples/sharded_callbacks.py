@@ -4,7 +4,11 @@ node-sharded over the GPUs of a node, serving ``constraints(free)`` /
 ``jacobian(free)`` to the process that runs the NLP solver.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \\
-        --master-addr 127.0.0.1 examples/sharded_callbacks.py [num_nodes]
+        --master-addr 127.0.0.1 examples/sharded_callbacks.py [num_nodes] [gait]
+
+(``gait``: the gait-like problem instead -- variable duration, a known and an
+unknown input trajectory, instance constraints with periodic two-atom pairs;
+its instance tails are evaluated by the rank that assembles each vector.)
 
 Rank 0 plays the solver: it evaluates the callbacks of
 ``opty_amd.ShardedProblem`` at a few points (IPOPT would, through
@@ -43,7 +47,11 @@ def main():
         dist.init_process_group('nccl',
                                 device_id=torch.device('cuda', local))
     torch.cuda.set_device(local)
-    kw = problems.n_link_cart_pendulum(num_links=10, num_nodes=num_nodes)
+    if 'gait' in sys.argv[2:]:
+        kw = problems.gait_like_pendulum(num_links=10, num_nodes=num_nodes)
+    else:
+        kw = problems.n_link_cart_pendulum(num_links=10,
+                                           num_nodes=num_nodes)
     # any objective: the callbacks under test are the constraints
     prob = opty_amd.ShardedProblem(lambda free: float(free @ free),
                                    lambda free: 2.0*free, device=local, **kw)
@@ -52,7 +60,9 @@ def main():
         dist.destroy_process_group()
         return
     rows, cols = prob.jacobianstructure()
-    frees = [problems.make_free(prob.num_free, seed=s) for s in range(3)]
+    vd = prob.collocator._variable_duration
+    frees = [problems.make_free(prob.num_free, seed=s, variable_duration=vd)
+             for s in range(3)]
     prob.constraints(frees[0]), prob.jacobian(frees[0])
     t0 = time.perf_counter()
     reps = 10
