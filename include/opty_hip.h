@@ -190,8 +190,10 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
                                double *host_jac, int64_t node_begin,
                                int64_t node_end);
 /* Host threads of the scatter pool (per process; 0 = the default:
- * OPTY_HIP_HOST_THREADS, or min(16, hardware threads / 2 / LOCAL_WORLD_SIZE)
- * -- the ranks of a node share its cores).  The workers run on the cores of
+ * OPTY_HIP_HOST_THREADS, or min(16, hardware threads / 4 / LOCAL_WORLD_SIZE)
+ * -- the ranks of a node share the cores of the NUMA node that holds the one
+ * vector they all scatter into; each worker gets a core of its own there,
+ * LOCAL_RANK deciding which).  The workers run on the cores of
  * the NUMA node that holds the caller's dense vector (get_mempolicy);
  * OPTY_HIP_HOST_NUMA=<node> overrides, =off leaves them where the creating
  * thread may run. */

@@ -26,6 +26,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/opty_hip.h"
@@ -206,16 +207,25 @@ public:
             const int n = atoi(env);
             if (n > 0) return std::min(n, 256);
         }
-        // one pool per process: the ranks of a node share its cores
-        unsigned ranks = 1;
-        if (const char *env = getenv("LOCAL_WORLD_SIZE"))
-            ranks = (unsigned)std::max(1, atoi(env));
+        // one pool per process: the ranks of a node share its cores, and all
+        // of them scatter into ONE vector, i.e. onto the cores of one NUMA
+        // node (a quarter of the hardware threads on a two-socket SMT box)
         const unsigned hw = std::thread::hardware_concurrency();
-        return (int)std::max(2u, std::min(16u, hw/2/ranks));
+        return (int)std::max(2u, std::min(16u, hw/4/local_ranks().second));
     }
 
     int threads() const { return (int)workers_.size(); }
     int numa_node() const { return node_; }
+
+    // (LOCAL_RANK, LOCAL_WORLD_SIZE) of this process (torch.distributed.run)
+    static std::pair<unsigned, unsigned> local_ranks() {
+        unsigned rank = 0, size = 1;
+        if (const char *env = getenv("LOCAL_WORLD_SIZE"))
+            size = (unsigned)std::max(1, atoi(env));
+        if (const char *env = getenv("LOCAL_RANK"))
+            rank = (unsigned)std::max(0, atoi(env)) % size;
+        return {rank, size};
+    }
 
     // CPUs of NUMA node `node` (the one that holds the vector being
     // assembled); restarts the workers there.  node < 0: unknown, nothing
@@ -316,14 +326,16 @@ private:
         // (OMP_PROC_BIND) pins the thread that loads this library to ONE
         // core, and sixteen workers on one core turn 5.9 ms into 40.
         cpu_set_t mask;
-        if (have_cpus_ && (int)cores_.size() >= 2*T) {
-            // a core of its own, the workers spread evenly over the node
-            // (its CCDs / memory channels); core 0 of the spread is left to
-            // whoever else runs there
-            const int n = (int)cores_.size();
+        const auto lr = local_ranks();
+        const long long all = (long long)T*lr.second;   // workers of the node
+        if (have_cpus_ && (long long)cores_.size() >= all) {
+            // a core of its own, the workers of all local ranks spread evenly
+            // over the node (its CCDs / memory channels)
+            const long long n = (long long)cores_.size();
+            const long long g = (long long)lr.first*T + t;
             cpu_set_t one;
             CPU_ZERO(&one);
-            CPU_SET(cores_[(size_t)((long long)(2*t + 1)*n/(2*T)) % n], &one);
+            CPU_SET(cores_[(size_t)(((2*g + 1)*n/(2*all)) % n)], &one);
             (void)sched_setaffinity(0, sizeof one, &one);
         } else if (have_cpus_) {
             (void)sched_setaffinity(0, sizeof cpus_, &cpus_);
