@@ -11,7 +11,8 @@ from tune_jac import parse
 from opty_amd.codegen.emit_hip import EmitOptions
 spec = sys.argv[1] if len(sys.argv) > 1 else 'default'
 what = {'jac': hb.EVAL_JAC, 'con': hb.EVAL_CON, 'fused': hb.EVAL_FUSED}[sys.argv[2] if len(sys.argv) > 2 else 'jac']
-opts = EmitOptions() if spec == 'default' else parse(spec)
+# 'default': what a collocator builds by itself (launch plan, spill-free cut)
+opts = None if spec == 'default' else parse(spec)
 workload = os.environ.get('OPTY_WORKLOAD', 'config3_10link')
 col = opty_amd.ConstraintCollocator(emit_options=opts, **problems.build(workload))
 hip = col.hip
