@@ -567,9 +567,14 @@ class ShardedCollocator(object):
     def to_host(self, con_host, jac_host):
         """Copies this rank's shard into the node-wide host vectors
         (:class:`SharedHostVector` of ``M*(N-1) + o`` and ``P*(N-1) +
-        nnz_inst`` doubles; None skips one) over this rank's own PCIe link;
-        asynchronous on the current stream.  Rank :attr:`tail_rank` also
-        evaluates and writes the instance tails."""
+        nnz_inst`` doubles; None skips one) over this rank's own PCIe link.
+        Enqueued on the current stream; a large Jacobian shard (the HIP
+        evaluator, ``_PACKED_MIN_VALUES``) is moved by
+        ``opty_hip_shard_jac_to_host`` instead -- only its varying entries
+        after the first time -- which returns when the shard has landed.
+        Synchronise the stream before reading the host vectors either way.
+        Rank :attr:`tail_rank` also evaluates and writes the instance
+        tails."""
         what = 'both' if (con_host is not None and jac_host is not None) \
             else ('con' if con_host is not None else 'jac')
         con, jac = (self._own_views(what) if self._in_place
