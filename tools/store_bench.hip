@@ -183,13 +183,16 @@ float time_ms(F launch, int iters = 20) {
     return ms/iters;
 }
 
-int main() {
-    const long long nnodes = 99999;
+// usage: store_bench.bin [row doubles (990)] [nodes (99999)]: the strip
+// pattern of a P = row block (the 24-link stand-in: 5100 49999)
+int main(int argc, char **argv) {
+    const long long arg_row = argc > 1 ? atoll(argv[1]) : 990;
+    const long long nnodes = argc > 2 ? atoll(argv[2]) : 99999;
     double *out;
-    const long long max_row = 1024;
+    const long long max_row = arg_row > 1024 ? arg_row + 8 : 1024;
     CHECK(hipMalloc(&out, nnodes*max_row*8 + 4096));
     const int grid = (int)((nnodes + 63)/64);
-    for (long long row : {990LL, 992LL}) {
+    for (long long row : {arg_row, arg_row + 2}) {
         const double gb = nnodes*row*8/1e9;
         for (int lds_kb : {36}) {
             const size_t lds = lds_kb*1024;
@@ -209,9 +212,10 @@ int main() {
         }
     }
     {
-        const long long row = 990;
+        const long long row = arg_row;
         const double gb = nnodes*row*8/1e9;
-        for (int G : {1, 4, 8}) {
+        for (int G : {1, 4, 8, 20, 32}) {
+            if (G > 8 && row < 2000) continue;
             const int nblk = (int)(((nnodes + 63)/64 + 7)/8*8);
             for (int lds_kb : {16, 36}) {
                 const size_t lds = lds_kb*1024;
@@ -231,7 +235,7 @@ int main() {
         }
     }
     {
-        const long long row = 990;
+        const long long row = arg_row;
         const double gb = nnodes*row*8/1e9;
         const int nblk = (int)((nnodes + 63)/64);
         for (int seg : {256, 512, 1024}) {
@@ -243,7 +247,7 @@ int main() {
             printf("chunk-per-block seg%d  %.4f ms %7.0f GB/s (%d blocks)\n", seg, ms, gb/ms*1e3*(nchunk*seg)/(row*8.0), nblk*nchunk);
         }
     }
-    const long long n2 = nnodes*990/2;
+    const long long n2 = nnodes*arg_row/2;
     for (int nb : {512, 2048, 8192}) {
         const long long per_block = (n2 + nb - 1)/nb;
         float ms = time_ms([&] { hipLaunchKernelGGL(contig256, dim3(nb), dim3(256), 0, 0, (double2 *)out, n2, per_block); });
