@@ -28,7 +28,8 @@ def parse(spec):
     kw = {}
     for item in filter(None, spec.split(',')):
         k, v = item.split('=')
-        kw[k] = None if v == 'None' else (v if k == 'ablate' else int(v))
+        kw[k] = None if v == 'None' else (
+            v if k in ('ablate', 'con_split', 'small_flush') else int(v))
     return EmitOptions(**kw)
 
 
