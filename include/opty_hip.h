@@ -89,6 +89,10 @@ typedef struct opty_hip_desc {
                              order jac[i*P + e]; OPTY_HIP_LAYOUT_CSR: sorted by
                              row then column, jac[S_j*(N-1) + i*L_j + pos]
                              (needs opty_hip_set_block_pattern)              */
+    int32_t inst_folded;  /* 1: opty_con / opty_jac / opty_conjac evaluate the
+                             instance tails themselves when launched with one
+                             workgroup more than the node blocks need (small
+                             problems: saves the launch of opty_inst)        */
 } opty_hip_desc;
 
 /* Loads the code object and allocates the device-side state (known

@@ -42,6 +42,14 @@ LINE_MODE_MIN_P = 64
 #: csr layout: rows up to this many entries are staged whole and written
 #: as one contiguous span per wave (tile = 65*8 bytes per entry)
 CSR_MAX_ROW = 64
+#: bytes of one evaluation up to which the runtime's host-buffer entry points
+#: use mapped host memory (OPTY_LATENCY_PATH_BYTES in csrc/opty_hip.cpp)
+LATENCY_PATH_BYTES = 2 << 20
+
+#: node-invariant operations up to which a small problem evaluates them in
+#: every lane instead of launching opty_uni before every evaluation
+INLINE_UNIFORM_MAX_NODES = 64
+
 #: workgroups the runtime launches opty_uni with (OPTY_UNI_WORKGROUPS in
 #: opty_hip.cpp)
 UNI_WORKGROUPS = 16
@@ -86,7 +94,22 @@ class EmitOptions(object):
     def __init__(self, chunk=32, groups=None, max_live=125, ablate=None,
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
-                 fused_groups=None, small_flush='flat', con_split='work'):
+                 fused_groups=None, small_flush='flat', con_split='work',
+                 fold_instance=None, inline_uniform=None):
+        # node-invariant sub-expressions evaluated by every lane instead of
+        # read from the table opty_uni fills: None = automatic (small
+        # problems whose table depends on `free` -- unknown parameters,
+        # variable duration -- and would cost a launch of opty_uni in every
+        # evaluation), 0 / 1 = never / always
+        self.inline_uniform = None if inline_uniform is None \
+            else int(bool(inline_uniform))
+        # instance-constraint tails evaluated by one extra workgroup of the
+        # main kernels instead of a launch of opty_inst: None = automatic
+        # (problems small enough for the runtime's latency path, where a
+        # launch costs as much as the evaluation: emit_module), 0 / 1 = never
+        # / always
+        self.fold_instance = None if fold_instance is None \
+            else int(bool(fold_instance))
         # how the constraint rows are cut into waves: 'work' balances the
         # waves' operation counts (_constraint_waves), 'count' gives every
         # wave the same number of rows (the fallback when the balanced cut
@@ -167,7 +190,11 @@ class EmitOptions(object):
                 (' fused_groups=%d' % self.fused_groups
                  if self.fused_groups is not None else '') +
                 ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
-                ('' if self.con_split == 'work' else ' con_split=count'))
+                ('' if self.con_split == 'work' else ' con_split=count') +
+                ('' if self.fold_instance is None
+                 else ' fold_instance=%d' % self.fold_instance) +
+                ('' if self.inline_uniform is None
+                 else ' inline_uniform=%d' % self.inline_uniform))
 
 
 def _lit(v):
@@ -390,10 +417,13 @@ def _max_live(dag, chunks, is_leaf):
 
 class _ModuleWriter(object):
 
-    def __init__(self, prog, opts):
+    def __init__(self, prog, opts, inline_uniform=False):
         self.p = prog
         self.o = opts
         self.dag = prog.dag
+        # True: no uni[] table -- node-invariant INPUTs are scalar loads from
+        # their homes and what depends on them is computed in every lane
+        self.inline_uni = bool(inline_uniform)
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
         self._auto = None           # (G_live, G) of group_ranges()
         self._con_nt = False        # constraint stores of the kernel in print
@@ -404,7 +434,10 @@ class _ModuleWriter(object):
             self.dag.args[i][0] in ('cur', 'adj')
 
     def _uniform_leaf(self, i):
-        """Non-constant node-invariant node: lives in the ``uni`` table."""
+        """Non-constant node-invariant node: lives in the ``uni`` table
+        (without a table: only the scalar inputs are leaves)."""
+        if self.inline_uni:
+            return self.dag.uni[i] and self.dag.op[i] == ir.INPUT
         return self.dag.uni[i] and self.dag.op[i] != ir.CONST
 
     def _slot(self, i):
@@ -633,6 +666,8 @@ class _ModuleWriter(object):
                 off = p.cur_offset if kind == 'cur' else p.adj_offset
                 return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
             if self._uniform_leaf(i):
+                if self.inline_uni:
+                    return self._scalar_source(i)
                 # diagnostics (wrong values): what would the kernel cost if
                 # node-invariant operands were literals / free?
                 if self.o.ablate == 'uni_lit':
@@ -863,11 +898,15 @@ class _ModuleWriter(object):
     (void)ncn;
 '''
 
-    def kernel(self, name, groups, con_of_group, W=1, con_nt=False):
+    def kernel(self, name, groups, con_of_group, W=1, con_nt=False,
+               inst_lines=None):
         """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
         wave; ``con_of_group[g]`` = constraint rows stored by wave g.  A
         workgroup is ``W`` consecutive groups of one 64-node block: they share
-        one input slab (filled cooperatively) and each owns a ring tile."""
+        one input slab (filled cooperatively) and each owns a ring tile.
+        ``inst_lines``: body of the instance-constraint tails, run by lane 0
+        of the first workgroup AFTER the node blocks' (the runtime launches
+        it only with whole-problem evaluations)."""
         G = len(groups)
         self._con_nt = bool(con_nt)
         keep = [True]*G
@@ -914,9 +953,15 @@ class _ModuleWriter(object):
         src = ['extern "C" __global__ void __launch_bounds__(%d)%s'
                % (64*W, occ),
                '%s(%s)' % (name, KERNEL_PARAMS), '{',
-               '    __shared__ double lds[%d];' % lds_doubles,
-               self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
-                                     slab=len(rows)*TS, ring=ring_rows*TS)]
+               '    __shared__ double lds[%d];' % lds_doubles]
+        if inst_lines:
+            src += ['    if (blockIdx.x >= ((node_end - node_begin + 63)/64 + '
+                    '7)/8*8*%d) {' % sets,
+                    '        if (threadIdx.x == 0) {']
+            src += ['            ' + ln for ln in inst_lines]
+            src += ['        }', '        return;', '    }']
+        src += [self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
+                                      slab=len(rows)*TS, ring=ring_rows*TS)]
         src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
         if G == 1:
             src += ['    ' + ln for ln in bodies[0]]
@@ -993,7 +1038,10 @@ class _ModuleWriter(object):
                       for i in needed)
         return '\n'.join(src), len(slots), dynamic
 
-    def inst_kernel(self):
+    def inst_lines(self):
+        """Statements storing the instance-constraint values and partials
+        (one lane; ``con`` / ``jac`` / ``con_stride`` / the node range of a
+        whole-problem launch)."""
         p, d = self.p, self.dag
         roots = list(p.inst_con_out) + list(p.inst_jac_out)
         needed = set(d.reachable(roots))
@@ -1013,10 +1061,13 @@ class _ModuleWriter(object):
             body.lines.append('if (jac) jac[(node_end - node_begin)*%dLL + '
                               '%d] = %s;' % (p.P, k, ref))
         body.end_scope()
+        return list(body.lines)
+
+    def inst_kernel(self):
         src = ['extern "C" __global__ void __launch_bounds__(64)',
                'opty_inst(%s)' % KERNEL_PARAMS, '{',
                '    if (threadIdx.x != 0 || blockIdx.x != 0) return;']
-        src += ['    ' + ln for ln in body.lines] + ['}']
+        src += ['    ' + ln for ln in self.inst_lines()] + ['}']
         return '\n'.join(src), dict(name='opty_inst', groups=1, lds_bytes=0)
 
 
@@ -1197,7 +1248,20 @@ def emit_module(prog, opts=None, node_blocks=None):
     launches this module is built for (picks the strip count of small
     launches, see ``_fit_one_round``); None = large launches."""
     opts = opts or EmitOptions()
-    w = _ModuleWriter(prog, opts)
+    # Small problems (see ``fold`` below) whose node-invariant table would be
+    # refilled by opty_uni before every evaluation do without the table.
+    inline = opts.inline_uniform
+    if inline is None:
+        rows = len(prog.rows)
+        inline = bool(node_blocks) and \
+            8*64*int(node_blocks)*(prog.P + prog.M + rows) \
+            <= LATENCY_PATH_BYTES and \
+            (prog.h[0] != 'fixed' or
+             any(src != 'known' for src, _ in prog.pars)) and \
+            sum(1 for i in range(len(prog.dag.op)) if prog.dag.uni[i] and
+                prog.dag.op[i] not in (ir.CONST, ir.INPUT)) \
+            <= INLINE_UNIFORM_MAX_NODES
+    w = _ModuleWriter(prog, opts, inline)
     groups = w.group_ranges()
     # Constraint rows may be split over several waves (contiguous row ranges):
     # one wave evaluating all M defects of a big system runs out of registers.
@@ -1247,7 +1311,7 @@ def emit_module(prog, opts=None, node_blocks=None):
                                        int(node_blocks))
         if dual is not None:
             opts, fused = dual
-            w = _ModuleWriter(prog, opts)
+            w = _ModuleWriter(prog, opts, inline)
             groups = w.group_ranges(fused)
             alone_sets = con_sets = dual_sets
         elif node_blocks:
@@ -1288,6 +1352,18 @@ def emit_module(prog, opts=None, node_blocks=None):
     nt_alone = opts.con_nt != 0
     nt_fused = opts.con_nt == 1 or (opts.con_nt is None and
                                     con_bytes > CON_CACHE_BYTES)
+    # Small problems (everything one evaluation moves fits the runtime's
+    # latency path, OPTY_LATENCY_PATH_BYTES: BASELINE config 2) cost what
+    # their launches cost, so the instance tails ride in the main kernels'
+    # launch: one more workgroup instead of one more kernel.
+    fold = opts.fold_instance
+    if fold is None:
+        per_block = 8*64*int(node_blocks or 0)
+        fold = bool(node_blocks and prog.inst_con_out) and \
+            per_block*(prog.P + prog.M) <= LATENCY_PATH_BYTES and \
+            per_block*(prog.P + prog.M + len(w._kernel_rows(
+                fused_groups, con_of))) <= LATENCY_PATH_BYTES
+    folded = w.inst_lines() if (fold and prog.inst_con_out) else None
     for key, name, grp, cons, wpw, nt in (
             ('con', 'opty_con', [[(0, 0)]]*len(alone_sets), alone_sets, 1,
              nt_alone),
@@ -1295,7 +1371,7 @@ def emit_module(prog, opts=None, node_blocks=None):
              [[] for _ in range(len(groups) + opts.pad)], opts.waves, False),
             ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves,
              nt_fused)):
-        src, meta = w.kernel(name, grp, cons, wpw, nt)
+        src, meta = w.kernel(name, grp, cons, wpw, nt, inst_lines=folded)
         parts += [src, '']
         kernels[key] = meta
     if prog.inst_con_out:
@@ -1315,5 +1391,6 @@ def emit_module(prog, opts=None, node_blocks=None):
                 chunk=opts.chunk, P=prog.P, M=prog.M, C=prog.C,
                 geometry=seeds, layout=getattr(prog, 'layout', 'coo'),
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
+                inst_folded=bool(folded),
                 sha=hashlib.sha256(source.encode()).hexdigest())
     return source, meta

@@ -496,7 +496,7 @@ int order_streams(Handle *p) {
 // are `con_stride` doubles apart), `jac` at the shard's first block.
 int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
            int threads, const double *free_, double *con, double *jac,
-           const NodeRange &rg) {
+           const NodeRange &rg, bool inst_block = false) {
     KernelArgs a;
     a.free_ = free_;
     a.known_traj = p->d_known;
@@ -523,7 +523,9 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
         // node blocks padded to a multiple of the 8 XCDs (see the kernels'
         // prologue: block -> XCD placement); surplus workgroups exit at once
         const long long nblk = ((rg.end - rg.begin + 63)/64 + 7)/8*8;
-        grid = (unsigned)(nblk*wgs_per_block);
+        // inst_block: one more workgroup, which evaluates the instance-
+        // constraint tails (modules built with desc.inst_folded)
+        grid = (unsigned)(nblk*wgs_per_block) + (inst_block ? 1u : 0u);
         if (grid == 0) return 0;
     }
     HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, 0, p->stream,
@@ -556,18 +558,26 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
                                 nullptr, rg)) return rc;
         p->uni_dirty = false;
     }
+    // Small problems' modules carry the instance tails in the main kernels
+    // (one more workgroup instead of one more launch: a launch costs such a
+    // problem as much as its evaluation).
+    const bool tails = with_inst && p->d.num_inst > 0;
+    const bool folded = tails && p->d.inst_folded;
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block,
-                            64*p->d.con_waves_per_wg, free_, con, nullptr, rg))
+                            64*p->d.con_waves_per_wg, free_, con, nullptr, rg,
+                            folded))
             return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
-        if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac, rg))
+        if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac, rg,
+                            folded))
             return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
         if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
-                            64*p->d.fused_waves_per_wg, free_, con, jac, rg))
+                            64*p->d.fused_waves_per_wg, free_, con, jac, rg,
+                            folded))
             return rc;
-    if (with_inst && p->d.num_inst > 0) {
+    if (tails && !folded) {
         double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr
             : con + (long long)p->d.M*rg.con_stride;
         double *j = (what == OPTY_HIP_EVAL_CON) ? nullptr
@@ -636,6 +646,8 @@ int eval_mapped(opty_hip_problem *p, int what, const double *free_,
                 double *con, double *jac) {
     const bool want_con = what != OPTY_HIP_EVAL_JAC;
     const bool want_jac = what != OPTY_HIP_EVAL_CON;
+    const double t_in = std::chrono::duration<double, std::micro>(
+        std::chrono::steady_clock::now().time_since_epoch()).count();
     if (int rc = ensure_pinned(&p->h_free, (size_t)p->num_free())) return rc;
     double *dcon = nullptr, *djac = nullptr;
     if (want_con) {
@@ -654,14 +666,29 @@ int eval_mapped(opty_hip_problem *p, int what, const double *free_,
         }
     }
     if (int rc = order_streams(p)) return rc;
+    // OPTY_HIP_TRACE=1: where the time of one call goes (stderr)
+    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+    auto now = [] {
+        return std::chrono::duration<double, std::micro>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t0 = trace ? now() : 0.0;
     memcpy(p->h_free, free_, p->num_free()*sizeof(double));
+    const double t1 = trace ? now() : 0.0;
     if (int rc = eval_device(p, what, p->h_free, dcon, djac, whole(p), true))
         return rc;
+    const double t2 = trace ? now() : 0.0;
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    const double t3 = trace ? now() : 0.0;
     if (want_con && dcon == p->h_con)
         memcpy(con, p->h_con, p->num_con()*sizeof(double));
     if (want_jac && djac == p->h_jac)
         memcpy(jac, p->h_jac, p->nnz()*sizeof(double));
+    if (trace)
+        fprintf(stderr, "opty_hip: mapped evaluation %d: pointer queries "
+                "%.1f us, free in %.1f, launches %.1f, wait %.1f, results "
+                "out %.1f\n", what, t0 - t_in, t1 - t0, t2 - t1, t3 - t2,
+                now() - t3);
     return 0;
 }
 

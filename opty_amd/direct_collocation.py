@@ -568,7 +568,8 @@ class ConstraintCollocator(object):
         steps = []
         if geo['con_waves'] > 1 and opts.con_split == 'work':
             steps.append(0)
-        if geo['line_mode']:
+        if geo['line_mode'] or self._jacobian_layout == 'csr':
+            # (row-sorted blocks are cut at row starts: any count up to M)
             steps += [1, 2, 3, 4, 5, 6, 8, 10, 12]
 
         def attempt(d):
@@ -603,7 +604,10 @@ class ConstraintCollocator(object):
                     best = least
         if best[2]:
             logger.warning('kernels %s still spill vector registers to '
-                           'scratch memory', best[2])
+                           'scratch memory (%d states, %d entries per '
+                           'block, launches of %d blocks)', best[2],
+                           self.num_states, self._program.P,
+                           self._launch_blocks())
         return best[0], best[1]
 
     def tune_launch(self, **kwargs):
@@ -641,7 +645,8 @@ class ConstraintCollocator(object):
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
             device=self._device,
-            layout=1 if self._jacobian_layout == 'csr' else 0)
+            layout=1 if self._jacobian_layout == 'csr' else 0,
+            inst_folded=int(meta.get('inst_folded', False)))
 
     def _known_trajectory_array(self, free):
         vals = []

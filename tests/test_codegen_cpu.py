@@ -618,18 +618,23 @@ def test_varying_entries_against_the_reference_values(name):
             assert not tail & set(dag.reachable([prog.jac_out[e]]))
 
 
-@pytest.mark.parametrize('name,launch_nodes', [
-    ('config3_10link_small', None), ('config3_10link_small', 12500),
-    ('config5_standin_24link_small', None),
-    ('config5_standin_24link_small', 6250),
-    ('config5_gaitlike_24link_small', 6250), ('elementary_mid_small', None)])
-def test_built_kernels_do_not_spill_vector_registers(name, launch_nodes):
+@pytest.mark.parametrize('name,launch_nodes,layout', [
+    ('config3_10link_small', None, 'coo'),
+    ('config3_10link_small', 12500, 'coo'),
+    ('config5_standin_24link_small', None, 'coo'),
+    ('config5_standin_24link_small', None, 'csr'),
+    ('config5_standin_24link_small', 6250, 'coo'),
+    ('config5_gaitlike_24link_small', 6250, 'coo'),
+    ('elementary_mid_small', None, 'coo')])
+def test_built_kernels_do_not_spill_vector_registers(name, launch_nodes,
+                                                     layout):
     """The code object a collocator uses has no kernel that spills VECTOR
     registers to scratch memory (``ConstraintCollocator._build_code_object``
     re-cuts until that holds): builds of the 24-link systems that did spill
     returned wrong, run-to-run different values on MI355X
     (``hip_backend.vgpr_spills``)."""
     col = ConstraintCollocator(launch_nodes=launch_nodes,
+                               jacobian_layout=layout,
                                **problems.build(name))
     hsaco, meta = col._build_code_object()
     assert hb.vgpr_spills(hsaco) == {}
@@ -637,3 +642,47 @@ def test_built_kernels_do_not_spill_vector_registers(name, launch_nodes):
     for kern in ('opty_con', 'opty_jac', 'opty_conjac'):
         assert res[kern]['.private_segment_fixed_size'] == 0
         assert res[kern]['.vgpr_count'] <= 512
+
+
+def test_small_problems_are_single_launch_modules():
+    """Problems small enough for the runtime's latency path cost what their
+    launches cost: the instance tails ride in the main kernels (one more
+    workgroup, ``inst_folded``), and a node-invariant table that opty_uni
+    would refill before every evaluation (unknown parameters, variable
+    duration) is not used at all -- those values are computed in every lane.
+    Large launches keep the table and the separate opty_inst launch, and
+    their source does not change."""
+    # BASELINE config 2: 4 instance constraints, a static table
+    col = ConstraintCollocator(**problems.build('config2_pendulum'))
+    src, meta = col.generate_source()
+    assert meta['inst_folded'] and meta['num_uniform'] > 0
+    assert not meta['uniform_dynamic']
+    assert col._descriptor(meta)['inst_folded'] == 1
+    for kern in ('opty_con', 'opty_jac', 'opty_conjac'):
+        body = src[src.index(kern + '('):]
+        body = body[:body.index('\nextern "C"')]
+        assert 'if (blockIdx.x >= ((node_end - node_begin + 63)/64 + 7)' \
+            in body and 'con[2LL*con_stride + 3]' in body
+    # the launch opty_hip_eval_instance makes for node shards is still there
+    assert 'opty_inst(' in src
+    # unknown parameters / variable duration, small: no table
+    for name in ('msd_be_small', 'vardur_pendulum_small'):
+        col = ConstraintCollocator(**problems.build(name))
+        src, meta = col.generate_source()
+        assert meta['num_uniform'] == 0 and not meta['uniform_dynamic']
+        assert 'uni_c[' not in src
+        off = ConstraintCollocator(
+            emit_options=EmitOptions(inline_uniform=0, fold_instance=0),
+            **problems.build(name))
+        src0, meta0 = off.generate_source()
+        assert meta0['num_uniform'] > 0 and meta0['uniform_dynamic']
+        assert not meta0['inst_folded']
+    # the same systems at a size that is not small keep both
+    big = ConstraintCollocator(**dict(
+        problems.CONFIGS['config2_pendulum'][0](num_nodes=100001)))
+    src, meta = big.generate_source()
+    assert not meta['inst_folded'] and 'blockIdx.x >= ((node_end' not in src
+    # a table too large to recompute per lane stays a table
+    col = ConstraintCollocator(**problems.build(
+        'config5_gaitlike_24link_small'))
+    assert col.generate_source()[1]['num_uniform'] > 1000

@@ -14,6 +14,15 @@ col = opty_amd.ConstraintCollocator(**problems.build('config2_pendulum'))
 hip = col.hip
 cf, jf = col.generate_constraint_function(), col.generate_jacobian_function()
 free = problems.make_free(col.num_free)
+if 'trace' in sys.argv[1:]:
+    # child of the run below: OPTY_HIP_TRACE=1 prints the phases of each call
+    for fn in (cf, jf):
+        for _ in range(6):
+            fn(free)
+    sys.exit(0)
+print('launch geometry', hip.desc['num_uniform'], 'uniform values (dynamic: %s),'
+      % bool(hip.desc['uniform_dynamic']), hip.desc['num_inst'],
+      'instance constraints')
 con = np.empty(col.num_constraints)
 jac = hb.pinned_empty(hip.nnz)
 dev = torch.device('cuda:0')
@@ -35,3 +44,8 @@ print('jacobian(free) callback               %6.1f us' % med(lambda: jf(free)))
 print('  opty_hip_eval_jac, host buffers     %6.1f us' % med(lambda: hip.eval_jac(free, jac, hb.HOST)))
 print('  device pointers + synchronize       %6.1f us' % med(lambda: (hip.eval_jac(fd, jd, hb.DEVICE), hip.synchronize())))
 print('torch H2D 240 KB (pageable) + sync    %6.1f us' % med(lambda: (fd.copy_(torch.from_numpy(free)), torch.cuda.synchronize())))
+
+import subprocess
+sys.stdout.flush()
+subprocess.run([sys.executable, __file__, 'trace'],
+               env=dict(os.environ, OPTY_HIP_TRACE='1'))
