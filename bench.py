@@ -318,9 +318,11 @@ def host_path(kw, dev_index, reps=7):
             out['jac_dense_copy'] = med(
                 lambda f: col.hip.eval_jac(f, dense, hb.HOST), frees)
             del dense
-            from opty_amd.codegen.program import varying_entries
-            out['varying_entries_per_block'] = len(varying_entries(
-                col._build_program()))
+            from opty_amd.codegen.program import varying_copies
+            unique, copies = varying_copies(col._build_program())
+            out['varying_entries_per_block'] = len(unique) + len(copies)
+            # ... of which only the distinct expressions cross PCIe
+            out['moved_entries_per_block'] = len(unique)
             out['host_threads'] = hb.host_threads()
         out['jac' + label] = med(col.generate_jacobian_function(), frees)
         out['nnz' + label] = col.hip.nnz

@@ -180,6 +180,15 @@ int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
  * opty_hip_eval_jac. */
 int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
                                  int32_t count);
+/* Block entries that are the SAME expression as an earlier varying entry (a
+ * symmetric mass matrix; its entries in the columns of the current and of the
+ * adjacent node's speeds): they are not named as varying entries, do not cross
+ * PCIe, and the host threads fill entry dst[k] of every node's block from
+ * entry src[k] of the same block (dst ascending and not varying entries; src
+ * varying entries).  Call after opty_hip_set_varying_entries, which clears the
+ * list. */
+int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
+                              const int32_t *src, int32_t count);
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
                                  double *jac);
 /* The same for one node shard of a problem evaluated by several GPUs: the

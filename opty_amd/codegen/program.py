@@ -272,3 +272,25 @@ def varying_entries(prog):
         if not ok:
             out.append(e)
     return out
+
+
+def varying_copies(prog):
+    """Splits :func:`varying_entries` into the entries that have to be
+    evaluated / moved and the ones that are *the same expression* as an
+    earlier one (the same node of the hash-consed DAG: the mass matrix of a
+    multibody system is symmetric, and its entries appear in the columns of
+    the current and of the adjacent node's speeds).  Returns ``(unique,
+    copies)``: ``unique`` ascending entry numbers, ``copies`` a list of
+    ``(dst, src)`` with ``src`` in ``unique`` -- for the 10-link pendulum 275
+    unique entries and 55 copies of the 330 varying ones."""
+    first = {}
+    unique, copies = [], []
+    for e in varying_entries(prog):
+        node = prog.jac_out[e]
+        if node in first:
+            copies.append((e, first[node]))
+        else:
+            first[node] = e
+            unique.append(e)
+    return unique, copies
+

@@ -189,7 +189,9 @@ public:
         const double *packed = nullptr;   // [node][V]
         double *dense = nullptr;          // [node][P]
         const int *run_start = nullptr, *run_len = nullptr;
-        int nruns = 0, V = 0, chunks = 0;
+        // entries that repeat another entry of their node's block
+        const int *copy_dst = nullptr, *copy_src = nullptr;
+        int nruns = 0, V = 0, chunks = 0, ncopies = 0;
         long long P = 0, nodes = 0;
     };
 
@@ -231,6 +233,7 @@ public:
     // assembled); restarts the workers there.  node < 0: unknown, nothing
     // changes.
     void set_numa_node(int node) {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
         if (node < 0 || node == node_) return;
         char path[96], buf[4096];
         snprintf(path, sizeof path,
@@ -276,6 +279,7 @@ public:
     }
 
     void resize(int n) {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
         stop();
         n = std::max(1, std::min(n, 256));
         quit_ = false;
@@ -290,6 +294,9 @@ public:
     // The caller publishes chunks [0, c) as landed with ready(c) and finally
     // waits for the workers.
     void start(const Job &job) {
+        // one job at a time: handles used from different host threads share
+        // the pool (released by wait())
+        busy_.lock();
         job_ = job;
         ready_.store(0, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
@@ -303,6 +310,7 @@ public:
     void wait() {
         while (done_.load(std::memory_order_acquire) < threads())
             std::this_thread::yield();
+        busy_.unlock();
     }
 
 private:
@@ -369,6 +377,8 @@ private:
                                (size_t)j.run_len[r]*sizeof(double));
                         src += j.run_len[r];
                     }
+                    for (int k = 0; k < j.ncopies; ++k)
+                        dst[j.copy_dst[k]] = dst[j.copy_src[k]];
                 }
             }
             done_.fetch_add(1, std::memory_order_release);
@@ -382,6 +392,7 @@ private:
     std::vector<int> cores_;     // one CPU per physical core of that node
     std::vector<std::thread> workers_;
     std::mutex m_;
+    std::recursive_mutex busy_;   // a job, or a restart of the workers
     std::condition_variable cv_;
     unsigned long long epoch_ = 0;
     bool quit_ = false;
@@ -412,6 +423,7 @@ struct opty_hip_problem {
     hipStream_t last_stream = nullptr;   // stream of the last enqueued work
     // host-visible Jacobian by varying entries (opty_hip_eval_jac_persistent)
     std::vector<int> var_entries, run_start, run_len;
+    std::vector<int> copy_dst, copy_src;  // opty_hip_set_entry_copies
     int *d_var = nullptr;
     double *d_packed = nullptr, *h_packed = nullptr;
     // page-locked, device-mapped staging of the latency path (eval_mapped)
@@ -1533,6 +1545,8 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
     if (int rc = use_device(p)) return rc;
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
     p->var_entries.assign(entries, entries + count);
+    p->copy_dst.clear();
+    p->copy_src.clear();
     p->run_start.clear();
     p->run_len.clear();
     for (int v = 0; v < count; ++v) {
@@ -1550,6 +1564,32 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
         HIP_TRY(hipMemcpy(p->d_var, entries, count*sizeof(int),
                           hipMemcpyHostToDevice));
     }
+    p->static_valid = p->shard_valid = false;
+    return 0;
+}
+
+int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
+                              const int32_t *src, int32_t count) {
+    if (!p) return fail("null handle");
+    if (count < 0 || count > p->d.P) return fail("bad copy count %d", count);
+    if (count > 0 && (!dst || !src)) return fail("null entries");
+    const std::vector<int> &var = p->var_entries;
+    for (int k = 0; k < count; ++k) {
+        if (dst[k] < 0 || dst[k] >= p->d.P ||
+            (k > 0 && dst[k] <= dst[k - 1]))
+            return fail("copied entries must ascend within [0, %d)", p->d.P);
+        if (std::binary_search(var.begin(), var.end(), dst[k]))
+            return fail("entry %d is moved as a varying entry: it cannot be "
+                        "a copy as well", dst[k]);
+        if (!std::binary_search(var.begin(), var.end(), src[k]))
+            return fail("entry %d is copied from entry %d, which is not a "
+                        "varying entry (opty_hip_set_varying_entries)",
+                        dst[k], src[k]);
+    }
+    if (int rc = use_device(p)) return rc;
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    p->copy_dst.assign(dst, dst + count);
+    p->copy_src.assign(src, src + count);
     p->static_valid = p->shard_valid = false;
     return 0;
 }
@@ -1575,6 +1615,8 @@ static int host_numa_node(const void *addr) {
 // host memory (h_blocks, page-locked): all of it (`full`), or only the varying
 // entries -- packed on the device, copied in chunks, scattered by the host
 // threads while the next chunk is in flight.  Synchronous.
+static bool packing_pays(const opty_hip_problem *p);
+
 static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                                double *h_blocks, long long count, bool full) {
     const int V = (int)p->var_entries.size();
@@ -1585,6 +1627,24 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                                (size_t)count*P*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
         HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+        if (!p->copy_dst.empty() && packing_pays(p)) {
+            // later calls fill the repeated entries from their sources: the
+            // vector holds the same values from the first call on (the
+            // kernels evaluate both copies, possibly a rounding apart)
+            ScatterPool &pool = ScatterPool::instance();
+            pool.set_numa_node(host_numa_node(h_blocks));
+            ScatterPool::Job job;
+            job.dense = h_blocks;
+            job.copy_dst = p->copy_dst.data();
+            job.copy_src = p->copy_src.data();
+            job.ncopies = (int)p->copy_dst.size();
+            job.chunks = 1;
+            job.P = P;
+            job.nodes = count;
+            pool.start(job);
+            pool.ready(1);
+            pool.wait();
+        }
         return 0;
     }
     if (V == 0) return 0;       // a block of constants: nothing moves
@@ -1633,6 +1693,9 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     job.run_start = p->run_start.data();
     job.run_len = p->run_len.data();
     job.nruns = (int)p->run_start.size();
+    job.copy_dst = p->copy_dst.data();
+    job.copy_src = p->copy_src.data();
+    job.ncopies = (int)p->copy_dst.size();
     job.V = V;
     job.chunks = chunks;
     job.P = P;

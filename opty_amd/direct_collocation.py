@@ -22,7 +22,7 @@ import sympy as sm
 import sympy.physics.mechanics as me
 
 from .utils import parse_free, sort_sympy
-from .codegen.program import build_program, varying_entries
+from .codegen.program import build_program, varying_copies
 from .codegen.emit_hip import emit_module, EmitOptions
 from . import hip_backend as hb
 
@@ -684,7 +684,14 @@ class ConstraintCollocator(object):
         if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
         if self._jacobian_layout == 'coo':
-            hip.set_varying_entries(varying_entries(self._program))
+            # entries that repeat another varying entry's expression are
+            # filled on the host (OPTY_HOST_NO_COPIES=1: moved like the rest)
+            import os
+            unique, copies = varying_copies(self._program)
+            if os.environ.get('OPTY_HOST_NO_COPIES') == '1':
+                unique, copies = sorted(unique + [d for d, _ in copies]), []
+            hip.set_varying_entries(unique)
+            hip.set_entry_copies(copies)
         if self.num_instance_constraints:
             idx = self.instance_constraints_free_index_map
             hip.set_instance_indices([idx[f] for f in self._inst_atoms],

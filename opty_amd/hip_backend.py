@@ -246,6 +246,7 @@ _SIGNATURES = {
         ctypes.c_int64]),
     'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_set_varying_entries': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
+    'opty_hip_set_entry_copies': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
     'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P]),
     'opty_hip_shard_jac_to_host': (ctypes.c_int, [
         _P, _P, _P, ctypes.c_int64, ctypes.c_int64]),
@@ -465,6 +466,14 @@ class HipProblem(object):
         e = np.ascontiguousarray(entries, dtype=np.int32)
         _check(self._lib.opty_hip_set_varying_entries(self._h, _ptr(e),
                                                       len(e)))
+
+    def set_entry_copies(self, copies):
+        """``[(dst, src), ...]``: block entries filled on the host from a
+        varying entry of the same block; see ``opty_hip_set_entry_copies``."""
+        dst = np.ascontiguousarray([d for d, _ in copies], dtype=np.int32)
+        src = np.ascontiguousarray([s for _, s in copies], dtype=np.int32)
+        _check(self._lib.opty_hip_set_entry_copies(self._h, _ptr(dst),
+                                                   _ptr(src), len(dst)))
 
     def eval_jac_persistent(self, free, jac):
         """``opty_hip_eval_jac_persistent``: host ``free``, page-locked

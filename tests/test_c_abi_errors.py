@@ -180,6 +180,18 @@ def test_round3_entry_points_reject_misuse():
         hip.set_varying_entries([1, 1])
     hip.set_varying_entries([])                     # a block of constants
     hip.set_varying_entries([0, 5])
+    # opty_hip_set_entry_copies: destinations ascend, are not moved
+    # themselves, and copy from an entry that is
+    with pytest.raises(hb.HipBackendError, match='not a varying entry'):
+        hip.set_entry_copies([(3, 2)])
+    with pytest.raises(hb.HipBackendError, match='cannot be a copy'):
+        hip.set_entry_copies([(5, 0)])
+    with pytest.raises(hb.HipBackendError, match='ascend'):
+        hip.set_entry_copies([(4, 0), (3, 5)])
+    with pytest.raises(hb.HipBackendError, match='ascend'):
+        hip.set_entry_copies([(P, 0)])
+    hip.set_entry_copies([(3, 0), (7, 5)])
+    hip.set_entry_copies([])
     free = problems.make_free(col.num_free)
     jac = hb.pinned_empty(hip.nnz)
     with pytest.raises(hb.HipBackendError, match='parameter'):

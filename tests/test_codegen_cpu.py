@@ -616,6 +616,17 @@ def test_varying_entries_against_the_reference_values(name):
             (dag.args[i][0] == 'h' and prog.h[0] != 'fixed'))}
         for e in static:
             assert not tail & set(dag.reachable([prog.jac_out[e]]))
+    # entries that repeat another one's expression (filled on the host from
+    # it, opty_hip_set_entry_copies) hold the same values in the reference's
+    # vector -- which evaluates each of them separately
+    from opty_amd.codegen.program import varying_copies
+    unique, copies = varying_copies(prog)
+    assert sorted(unique + [d for d, _ in copies]) == var
+    assert all(s in unique and s < d for d, s in copies)
+    for d, s in copies:
+        np.testing.assert_allclose(blk[:, d], blk[:, s], rtol=1e-13, atol=0)
+    if name == 'config3_10link_small':
+        assert (len(unique), len(copies)) == (275, 55)
 
 
 @pytest.mark.parametrize('name,launch_nodes,layout', [
