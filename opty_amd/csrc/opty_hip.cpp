@@ -1733,8 +1733,16 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
 
 // nothing to gain from packing: no table, or most of the block varies
 static bool packing_pays(const opty_hip_problem *p) {
+    static const double ratio = [] {
+        const char *env = getenv("OPTY_HIP_PACK_RATIO");
+        const double r = env ? atof(env) : 0.0;
+        // measured (pruned 10-link block, 275 of 390 stored entries:
+        // 5.94 ms whole blocks, 4.85 ms packed): the pack kernel and the
+        // host scatter cost less than the bytes they save well beyond half
+        return r > 0.0 && r <= 1.0 ? r : 0.8;
+    }();
     return p->d.layout == OPTY_HIP_LAYOUT_COO && p->d_var != nullptr &&
-           2*(long long)p->var_entries.size() <= p->P();
+           (double)p->var_entries.size() <= ratio*(double)p->P();
 }
 
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
