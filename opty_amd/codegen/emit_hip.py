@@ -95,7 +95,13 @@ class EmitOptions(object):
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
-                 fold_instance=None, inline_uniform=None):
+                 fold_instance=None, inline_uniform=None, dear_first=0):
+        # 1: the waves of a block are dispatched longest first -- constraint
+        # waves, then the Jacobian strips by descending evaluation work --
+        # instead of in entry order (a launch of a few rounds ends when its
+        # last LONG wave ends; with the cheap, store-only strips last the
+        # tail is short)
+        self.dear_first = int(dear_first)
         # node-invariant sub-expressions evaluated by every lane instead of
         # read from the table opty_uni fills: None = automatic (small
         # problems whose table depends on `free` -- unknown parameters,
@@ -194,7 +200,8 @@ class EmitOptions(object):
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
-                 else ' inline_uniform=%d' % self.inline_uniform))
+                 else ' inline_uniform=%d' % self.inline_uniform) +
+                (' dear_first=1' if self.dear_first else ''))
 
 
 def _lit(v):
@@ -884,7 +891,7 @@ class _ModuleWriter(object):
     // strips of the same output rows) go to the SAME XCD / L2, back to back.
     const long long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const long long blk = (slot/{sets})*8 + xcd;
-    const int grp = (int)(slot % {sets})*{W} + wave;
+    const int grp = (int)({rot} % {sets})*{W} + wave;
     if (blk >= nblk) return;
     const long long node0 = node_begin + blk*64;
     const long long node = node0 + lane;
@@ -899,14 +906,16 @@ class _ModuleWriter(object):
 '''
 
     def kernel(self, name, groups, con_of_group, W=1, con_nt=False,
-               inst_lines=None):
+               inst_lines=None, first_group=0):
         """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
         wave; ``con_of_group[g]`` = constraint rows stored by wave g.  A
         workgroup is ``W`` consecutive groups of one 64-node block: they share
         one input slab (filled cooperatively) and each owns a ring tile.
         ``inst_lines``: body of the instance-constraint tails, run by lane 0
         of the first workgroup AFTER the node blocks' (the runtime launches
-        it only with whole-problem evaluations)."""
+        it only with whole-problem evaluations).  ``first_group``: the
+        workgroup of a block that holds this wave is dispatched first, the
+        others follow cyclically."""
         G = len(groups)
         self._con_nt = bool(con_nt)
         keep = [True]*G
@@ -961,7 +970,9 @@ class _ModuleWriter(object):
             src += ['            ' + ln for ln in inst_lines]
             src += ['        }', '        return;', '    }']
         src += [self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
-                                      slab=len(rows)*TS, ring=ring_rows*TS)]
+                                      slab=len(rows)*TS, ring=ring_rows*TS,
+                                      rot='slot' if (first_group//W) % sets == 0 else
+                                      '(slot + %d)' % ((first_group//W) % sets))]
         src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
         if G == 1:
             src += ['    ' + ln for ln in bodies[0]]
@@ -1333,6 +1344,11 @@ def emit_module(prog, opts=None, node_blocks=None):
                  waves=opts.waves, occupancy=opts.occupancy,
                  line_mode=bool(w.line_mode()),
                  live=w.auto_groups()[0] if opts.groups is None else None)
+    if opts.dear_first:
+        def work(grp):
+            return sum(w._strip_cost(e0, e1) for e0, e1 in grp if e1 > e0)
+        groups = sorted(groups, key=work, reverse=True)
+        fused_jac = sorted(fused_jac, key=work, reverse=True)
     con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
@@ -1371,7 +1387,10 @@ def emit_module(prog, opts=None, node_blocks=None):
              [[] for _ in range(len(groups) + opts.pad)], opts.waves, False),
             ('conjac', 'opty_conjac', fused_groups, con_of, opts.waves,
              nt_fused)):
-        src, meta = w.kernel(name, grp, cons, wpw, nt, inst_lines=folded)
+        src, meta = w.kernel(
+            name, grp, cons, wpw, nt, inst_lines=folded,
+            first_group=len(fused_jac) if (opts.dear_first and
+                                           key == 'conjac') else 0)
         parts += [src, '']
         kernels[key] = meta
     if prog.inst_con_out:
