@@ -154,6 +154,12 @@ class Lowerer(object):
             return acc
         if isinstance(cond, sm.Not):
             return self._select(cond.args[0], y, x)
+        if isinstance(cond, sm.ITE):
+            # what SymPy folds a Piecewise nested in a Piecewise into:
+            # ITE(a, b, c) ? x : y  ==  a ? (b ? x : y) : (c ? x : y)
+            a, b, c = cond.args
+            return self._select(a, self._select(b, x, y),
+                                self._select(c, x, y))
         rels = {sm.Lt: ('lt', False), sm.Le: ('le', False),
                 sm.Gt: ('lt', True), sm.Ge: ('le', True),
                 sm.Eq: ('eq', False), sm.Ne: ('ne', False)}
