@@ -245,6 +245,38 @@ def elementary_functions(num_nodes=45, method='backward euler',
                 integration_method=method)
 
 
+def c99_functions(num_nodes=47, method='backward euler'):
+    """Not from the reference's examples: a 3-state system with the rest of
+    the C99 printer's function table (``sympy.printing.c.known_functions_C99``
+    beyond :func:`elementary_functions`): ``log1p``, ``expm1``, ``log2``,
+    ``log10``, ``exp2``, ``Cbrt``, ``hypot``, ``fma`` of
+    ``sympy.codegen.cfunctions`` and ``gamma`` / ``loggamma`` of a known
+    parameter (their derivative, digamma, has no C counterpart), with an
+    unknown input and an unknown parameter.  (``cfunctions.Sqrt`` is lowered
+    too, but SymPy 1.14's C printer raises ``KeyError: 'Sqrt'`` for it, so
+    the reference cannot build it.)"""
+    from sympy.codegen import cfunctions as cf
+    me.dynamicsymbols._t = sm.Symbol('t')
+    t = me.dynamicsymbols._t
+    a, g = sm.symbols('a, g', real=True)
+    x, y, z, u = me.dynamicsymbols('x, y, z, u', real=True)
+    eom = sm.Matrix([
+        x.diff() - (cf.log1p(y**2) + cf.expm1(-x**2/4)*u
+                    + cf.hypot(z, 1 + x*y)),
+        y.diff() - (cf.log2(2 + z**2)*a - cf.log10(3 + x**2)
+                    + cf.Cbrt(1 + y**2)*sm.gamma(g)),
+        z.diff() - (cf.exp2(-y**2)*sm.loggamma(g + 1) + cf.fma(x, y, u/2)
+                    - sm.sqrt(2 + z**2)),
+    ])
+    N = num_nodes
+    inst = (x.func(0.0) - 0.25, z.func((N - 1)*0.05) - 0.5)
+    return dict(equations_of_motion=eom, state_symbols=(x, y, z),
+                num_collocation_nodes=N, node_time_interval=0.05,
+                known_parameter_map={g: 2.6},
+                instance_constraints=inst, time_symbol=t,
+                integration_method=method)
+
+
 def piecewise_functions(num_nodes=53, method='backward euler'):
     """Not from the reference's examples: a 3-state system with the
     branching and special functions SymPy's C99 printer also accepts in
@@ -427,6 +459,8 @@ CONFIGS = {
     'delay_be_small': (delay_equation, {}),
     'delay_mid_small': (delay_equation, {'num_nodes': 66,
                                          'method': 'midpoint'}),
+    'c99_be_small': (c99_functions, {}),
+    'c99_mid_small': (c99_functions, {'method': 'midpoint'}),
     'elementary_be_small': (elementary_functions, {}),
     'elementary_mid_small': (elementary_functions,
                              {'num_nodes': 70, 'method': 'midpoint',

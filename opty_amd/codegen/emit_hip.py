@@ -1153,7 +1153,9 @@ def _dual_occupancy_cut(prog, writer, opts, live_groups, con_waves,
 _OP_WEIGHT = {'sin': 18, 'cos': 18, 'tan': 60, 'exp': 30, 'log': 35,
               'sqrt': 12, ir.DIV: 12, ir.POW: 90, ir.ATAN2: 80, 'asin': 60,
               'acos': 60, 'atan': 50, 'sinh': 60, 'cosh': 60, 'tanh': 60,
-              'erf': 60, 'erfc': 60, 'asinh': 70, 'acosh': 70, 'atanh': 70}
+              'erf': 60, 'erfc': 60, 'asinh': 70, 'acosh': 70, 'atanh': 70,
+              'log1p': 40, 'expm1': 40, 'log2': 35, 'log10': 35, 'exp2': 30,
+              'cbrt': 40, 'tgamma': 120, 'lgamma': 120}
 
 
 def _node_weight(dag, i):

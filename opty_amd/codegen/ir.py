@@ -29,7 +29,11 @@ SELECT = 'select'    # args: (rel, a, b, x, y): (a rel b) ? x : y
 RELATIONS = ('lt', 'le', 'eq', 'ne')
 UNARY = ('sqrt', 'sin', 'cos', 'tan', 'exp', 'log', 'abs', 'sign', 'asin',
          'acos', 'atan', 'sinh', 'cosh', 'tanh', 'step', 'erf', 'erfc',
-         'floor', 'ceil', 'asinh', 'acosh', 'atanh')
+         'floor', 'ceil', 'asinh', 'acosh', 'atanh',
+         # the rest of the C99 printer's table (sympy.codegen.cfunctions,
+         # gamma / loggamma): printed under their C names
+         'log1p', 'expm1', 'log2', 'log10', 'exp2', 'cbrt', 'tgamma',
+         'lgamma')
 #: ``step(x)`` is 1 for x > 0 else 0 (used for d max / d min).
 
 #: kinds of INPUT nodes.  ``cur``/``adj`` are the per-node values of a
@@ -221,11 +225,15 @@ class DAG(object):
              'step': lambda v: 1.0 if v > 0 else 0.0,
              'erf': math.erf, 'erfc': math.erfc, 'floor': math.floor,
              'ceil': math.ceil, 'asinh': math.asinh, 'acosh': math.acosh,
-             'atanh': math.atanh}
+             'atanh': math.atanh, 'log1p': math.log1p, 'expm1': math.expm1,
+             'log2': math.log2, 'log10': math.log10,
+             'tgamma': math.gamma, 'lgamma': math.lgamma}
+    # (exp2 / cbrt of a constant are left to the device: Python 3.10 has no
+    # correctly rounded counterpart of C's)
 
     def unary(self, name, a):
         assert name in UNARY, name
-        if self.is_const(a):
+        if self.is_const(a) and name in self._FOLD:
             try:
                 return self.const(self._FOLD[name](self.value(a)))
             except (ValueError, OverflowError):
@@ -233,7 +241,7 @@ class DAG(object):
         if self.op[a] == NEG:
             x = self.args[a][0]
             if name in ('sin', 'tan', 'asin', 'atan', 'sinh', 'tanh',
-                        'sign', 'erf', 'asinh', 'atanh'):
+                        'sign', 'erf', 'asinh', 'atanh', 'cbrt'):
                 return self.neg(self.unary(name, x))
             if name in ('cos', 'cosh', 'abs'):
                 return self.unary(name, x)

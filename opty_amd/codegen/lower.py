@@ -24,6 +24,15 @@ _UNARY_FUNCS = {
     sm.ceiling: 'ceil', sm.asinh: 'asinh', sm.acosh: 'acosh',
     sm.atanh: 'atanh',
 }
+try:
+    from sympy.codegen import cfunctions as _cf
+    _UNARY_FUNCS.update({_cf.log1p: 'log1p', _cf.expm1: 'expm1',
+                         _cf.log2: 'log2', _cf.log10: 'log10',
+                         _cf.exp2: 'exp2', _cf.Cbrt: 'cbrt',
+                         _cf.Sqrt: 'sqrt'})
+except ImportError:                     # pragma: no cover
+    _cf = None
+_UNARY_FUNCS.update({sm.gamma: 'tgamma', sm.loggamma: 'lgamma'})
 #: printed by the reference's C99 printer as 1/cos, 1/sin, cos/sin ...
 _RECIPROCAL_FUNCS = {sm.sec: 'cos', sm.csc: 'sin', sm.sech: 'cosh',
                      sm.csch: 'sinh'}
@@ -111,6 +120,16 @@ class Lowerer(object):
             for a in e.args[1:]:
                 acc = d.binary(name, acc, m[a])
             return acc
+        if _cf is not None and f is _cf.hypot:
+            a, b = m[e.args[0]], m[e.args[1]]
+            return d.unary('sqrt', d.add(d.mul(a, a), d.mul(b, b)))
+        if _cf is not None and f is _cf.fma:
+            return d.add(d.mul(m[e.args[0]], m[e.args[1]]), m[e.args[2]])
+        if f is sm.sinc:
+            # the C printer's ((x != 0) ? sin(x)/x : 1)
+            x = m[e.args[0]]
+            return d.select('ne', x, d.zero, d.div(d.unary('sin', x), x),
+                            d.one)
         if f is sm.Heaviside:
             return d.unary('step', m[e.args[0]])
         if f in _RECIPROCAL_FUNCS:
@@ -332,7 +351,21 @@ def forward_jacobian(dag, outputs, wrt_inputs, chain=None):
                     f = d.unary('sinh', x)
                 elif op == 'tanh':
                     f = d.sub(d.one, d.mul(i, i))
+                elif op == 'log1p':
+                    f = d.div(d.one, d.add(d.one, x))
+                elif op == 'expm1':
+                    f = d.add(i, d.one)
+                elif op == 'log2':      # 1/(x ln 2)
+                    f = d.div(d.const(1.4426950408889634), x)
+                elif op == 'log10':     # 1/(x ln 10)
+                    f = d.div(d.const(0.4342944819032518), x)
+                elif op == 'exp2':      # ln 2 * 2^x
+                    f = d.mul(d.const(0.6931471805599453), i)
+                elif op == 'cbrt':      # 1/(3 cbrt(x)^2)
+                    f = d.div(d.one, d.mul(d.const(3.0), d.mul(i, i)))
                 else:
+                    # tgamma / lgamma: their derivative (digamma) has no C
+                    # counterpart -- the reference cannot print it either
                     raise LoweringError('no derivative rule for %s' % op)
                 g = scaled(ga, f) if f != zero else {}
         # drop structural zeros that simplification produced

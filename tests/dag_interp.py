@@ -14,13 +14,18 @@ _UN = {'sqrt': np.sqrt, 'sin': np.sin, 'cos': np.cos, 'tan': np.tan,
        'sinh': np.sinh, 'cosh': np.cosh, 'tanh': np.tanh,
        'step': lambda x: (x > 0).astype(float),
        'floor': np.floor, 'ceil': np.ceil, 'asinh': np.arcsinh,
-       'acosh': np.arccosh, 'atanh': np.arctanh}
+       'acosh': np.arccosh, 'atanh': np.arctanh, 'log1p': np.log1p,
+       'expm1': np.expm1, 'log2': np.log2, 'log10': np.log10,
+       'exp2': np.exp2, 'cbrt': np.cbrt}
 try:
-    from scipy.special import erf as _erf, erfc as _erfc
-    _UN.update(erf=_erf, erfc=_erfc)
+    from scipy.special import erf as _erf, erfc as _erfc, gamma as _gamma, \
+        gammaln as _gammaln
+    _UN.update(erf=_erf, erfc=_erfc, tgamma=_gamma, lgamma=_gammaln)
 except ImportError:                     # pragma: no cover
     import math
-    _UN.update(erf=np.vectorize(math.erf), erfc=np.vectorize(math.erfc))
+    _UN.update(erf=np.vectorize(math.erf), erfc=np.vectorize(math.erfc),
+               tgamma=np.vectorize(math.gamma),
+               lgamma=np.vectorize(math.lgamma))
 _REL = {'lt': np.less, 'le': np.less_equal, 'eq': np.equal,
         'ne': np.not_equal}
 
@@ -78,7 +83,19 @@ _DUN = {'sqrt': lambda x, f: 0.5/f, 'sin': lambda x, f: np.cos(x),
         'erfc': lambda x, f: 1.1283791670955126*np.exp(-x*x),
         'asinh': lambda x, f: 1.0/np.sqrt(x*x + 1.0),
         'acosh': lambda x, f: 1.0/np.sqrt(x*x - 1.0),
-        'atanh': lambda x, f: 1.0/(1.0 - x*x)}
+        'atanh': lambda x, f: 1.0/(1.0 - x*x),
+        'log1p': lambda x, f: 1.0/(1.0 + x), 'expm1': lambda x, f: f + 1.0,
+        'log2': lambda x, f: 1.4426950408889634/x,
+        'log10': lambda x, f: 0.4342944819032518/x,
+        'exp2': lambda x, f: 0.6931471805599453*f,
+        'cbrt': lambda x, f: 1.0/(3.0*f*f),
+        'tgamma': lambda x, f: f*_digamma(x),
+        'lgamma': lambda x, f: _digamma(x)}
+
+
+def _digamma(x):
+    from scipy.special import digamma
+    return digamma(x)
 
 
 def evaluate_with_error_bound(dag, roots, inputs):

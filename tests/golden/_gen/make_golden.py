@@ -45,7 +45,8 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'vardur_pendulum_small', 'config5_standin_24link_small',
          'chaplygin_be_small', 'chaplygin_mid_small', 'one_eom_be_small',
          'one_eom_mid_small', 'implicit_traj_be_small',
-         'implicit_traj_mid_small', 'elementary_be_small',
+         'implicit_traj_mid_small', 'c99_be_small', 'c99_mid_small',
+         'elementary_be_small',
          'elementary_mid_small', 'delay_be_small', 'delay_mid_small',
          'odd_block_be_small', 'odd_block_mid_small',
          'piecewise_be_small', 'piecewise_mid_small',

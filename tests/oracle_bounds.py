@@ -19,6 +19,13 @@ multiple of it."""
 import numpy as np
 import sympy as sm
 
+#: lambdify name spaces: what the scipy / numpy printers do not know of the
+#: C99 printer's function table (sympy.codegen.cfunctions)
+_MODULES = [{'Cbrt': np.cbrt, 'hypot': np.hypot, 'exp2': np.exp2,
+             'log2': np.log2, 'log10': np.log10, 'log1p': np.log1p,
+             'expm1': np.expm1, 'fma': lambda a, b, c: a*b + c},
+            'scipy', 'numpy']
+
 
 class _Evaluator(object):
 
@@ -81,7 +88,7 @@ class _Evaluator(object):
             args = [self(a) for a in e.args]
             fn = sm.lambdify(sm.symbols('x0:%d' % len(args)),
                              e.func(*sm.symbols('x0:%d' % len(args))),
-                             ['scipy', 'numpy'])
+                             _MODULES)
             with np.errstate(all='ignore'):
                 v = fn(*[a[0] for a in args])
                 m = np.abs(v)
@@ -89,7 +96,7 @@ class _Evaluator(object):
                 for k, a in enumerate(args):
                     try:
                         d = sm.lambdify(xs, e.func(*xs).diff(xs[k]),
-                                        ['scipy', 'numpy'])
+                                        _MODULES)
                         dv = np.abs(d(*[b[0] for b in args]))
                     except Exception:
                         dv = 1.0

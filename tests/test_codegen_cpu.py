@@ -79,7 +79,14 @@ def test_forward_jacobian_against_sympy():
              sm.sqrt(a**2 + b**2 + 1)*sm.log(c**2 + 2), a**3*b**-2 + c**b,
              sm.atan2(a, b) + sm.asin(c/3) + sm.acos(c/4) + sm.atan(a*b),
              sm.sinh(a) + sm.cosh(b)*sm.tanh(c) + sm.Abs(a - b),
-             sm.Max(a, b*c) + sm.Min(a, b)]
+             sm.Max(a, b*c) + sm.Min(a, b),
+             sm.erf(a*b) + sm.erfc(c/2) + sm.asinh(a) + sm.acosh(1 + b)
+             + sm.atanh(c/3)]
+    # the rest of the C99 printer's table (sympy.codegen.cfunctions)
+    from sympy.codegen import cfunctions as cf
+    exprs += [cf.log1p(a*b) + cf.expm1(-c) + cf.log2(a + b) + cf.log10(c + 2),
+              cf.exp2(a - b)*cf.Cbrt(1 + c**2) + cf.hypot(a, b*c)
+              + cf.fma(a, b, c) + cf.Sqrt(a + c), sm.sinc(a*b)*c]
     d = ir.DAG()
     table = {s: d.input('cur', k) for k, s in enumerate((a, b, c))}
     low = Lowerer(d, table)
@@ -90,7 +97,8 @@ def test_forward_jacobian_against_sympy():
     num = dag_interp.evaluate(d, [n for row in jac for n in row],
                               lambda kind, k: vals[k])
     sym = sm.Matrix(exprs).jacobian([a, b, c])
-    f = sm.lambdify((a, b, c), sym, 'numpy')
+    import oracle_bounds
+    f = sm.lambdify((a, b, c), sym, oracle_bounds._MODULES)
     for i in range(50):
         ref = np.array(f(*vals[:, i]), dtype=float).ravel()
         got = np.array([np.broadcast_to(v, (50,))[i] for v in num])
@@ -697,3 +705,19 @@ def test_small_problems_are_single_launch_modules():
     col = ConstraintCollocator(**problems.build(
         'config5_gaitlike_24link_small'))
     assert col.generate_source()[1]['num_uniform'] > 1000
+
+
+def test_gamma_of_a_trajectory_has_no_derivative_rule():
+    """``gamma`` / ``loggamma`` are lowered (``tgamma`` / ``lgamma``), but
+    their derivative is the digamma function, which C -- and therefore the
+    reference's generated code -- does not have: usable on known parameters
+    (``c99_functions``), rejected where the Jacobian would need it."""
+    import sympy.physics.mechanics as me
+    from opty_amd.codegen.lower import LoweringError
+    t = sm.Symbol('t')
+    me.dynamicsymbols._t = t
+    x = me.dynamicsymbols('x', real=True)
+    eom = sm.Matrix([x.diff() + sm.gamma(2 + x**2)])
+    col = ConstraintCollocator(eom, (x,), 11, 0.1, time_symbol=t)
+    with pytest.raises(LoweringError, match='derivative'):
+        col.generate_source()
