@@ -803,3 +803,23 @@ def test_persistent_jacobian_moves_only_what_changed(name, N):
     finally:
         hb.set_host_threads(0)
     assert hb.host_threads() >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,layout', [
+    ('config3_10link_small', 'coo'), ('elementary_mid_small', 'coo'),
+    ('config5_standin_24link_small', 'csr')])
+def test_cross_check_against_another_compiler_pipeline(name, layout):
+    """``ConstraintCollocator.cross_check``: the build in use and an ``-O1``
+    twin of the same generated module agree to rounding on the first and last
+    nodes, for the caller's ``free`` or seeded random values."""
+    import opty_amd
+    col = opty_amd.ConstraintCollocator(jacobian_layout=layout,
+                                        **problems.build(name))
+    assert col.cross_check(window=17) <= 1e-12
+    free = problems.make_free(col.num_free, seed=3,
+                              variable_duration=col._variable_duration)
+    assert col.cross_check(free) <= 1e-12
+    # the collocator goes on working with its own build
+    z = col.generate_constraint_function()(free)
+    assert np.isfinite(z).all()
