@@ -138,6 +138,12 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     return hsaco
 
 
+#: hipcc switches of the last-resort build of a module whose kernels spill
+#: vector registers whatever the cut: without the scheduler stage that the
+#: wrong values of round 3 followed (profiles/r03_spill_incident.txt)
+SAFE_SCHEDULER_FLAGS = ('-mllvm',
+                        '-amdgpu-disable-unclustered-high-rp-reschedule')
+
 _RESOURCE_KEYS = ('.vgpr_count', '.agpr_count', '.sgpr_count',
                   '.vgpr_spill_count', '.sgpr_spill_count',
                   '.private_segment_fixed_size', '.group_segment_fixed_size')

@@ -721,3 +721,29 @@ def test_gamma_of_a_trajectory_has_no_derivative_rule():
     col = ConstraintCollocator(eom, (x,), 11, 0.1, time_symbol=t)
     with pytest.raises(LoweringError, match='derivative'):
         col.generate_source()
+
+
+def test_unavoidable_spills_fall_back_to_the_safe_scheduler(monkeypatch,
+                                                            caplog):
+    """When no cut of a module is free of vector-register spills, the
+    least-spilling one is built without the pre-RA scheduler stage that the
+    wrong values of round 3 followed (``hip_backend.SAFE_SCHEDULER_FLAGS``),
+    with a warning that names ``cross_check()``."""
+    import logging
+    col = ConstraintCollocator(**problems.build('msd_be_small'))
+    plain, _ = col._build_code_object()
+    calls = []
+    real = hb.compile_module
+
+    def spy(source, *args, **kw):
+        calls.append(tuple(kw.get('extra_flags', ())))
+        return real(source, *args, **kw)
+    monkeypatch.setattr(hb, 'compile_module', spy)
+    monkeypatch.setattr(hb, 'vgpr_spills',
+                        lambda hsaco, kernels=None: {'opty_conjac': 3})
+    with caplog.at_level(logging.WARNING, logger='opty_amd'):
+        hsaco, meta = col._build_code_object()
+    assert calls[-1] == hb.SAFE_SCHEDULER_FLAGS
+    assert all(c == () for c in calls[:-1])
+    assert hsaco != plain and os.path.exists(hsaco)
+    assert any('cross_check' in r.getMessage() for r in caplog.records)
