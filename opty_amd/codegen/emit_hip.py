@@ -939,6 +939,11 @@ class _ModuleWriter(object):
             else:
                 W = self._waves_per_workgroup(len(rows), ring_rows)
         W = max(1, min(W, G))
+        # a hand-set workgroup width that does not fit the CU's LDS (64-entry
+        # chunks of a 4-wave workgroup next to a large slab) is narrowed
+        # instead of failing in hipcc ("local memory exceeds limit")
+        while W > 1 and (len(rows) + W*ring_rows)*TS*8 > 160*1024:
+            W -= 1
         sets = (G + W - 1)//W
         bodies = [self._group_body(grp, con_of_group[g], slab_of)
                   if keep[g] else []

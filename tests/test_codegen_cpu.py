@@ -747,3 +747,17 @@ def test_unavoidable_spills_fall_back_to_the_safe_scheduler(monkeypatch,
     assert all(c == () for c in calls[:-1])
     assert hsaco != plain and os.path.exists(hsaco)
     assert any('cross_check' in r.getMessage() for r in caplog.records)
+
+
+def test_hand_set_workgroup_width_is_narrowed_to_the_lds():
+    """64-entry chunks in a 4-wave workgroup next to the slab of a 22-state
+    system need more than a CU's 160 KB of LDS: the printer narrows the
+    workgroup instead of leaving the failure to hipcc (found by
+    tools/geometry_soak.py)."""
+    col = ConstraintCollocator(
+        emit_options=EmitOptions(chunk=64, waves=4, groups=8),
+        **problems.build('config3_10link_small'))
+    src, meta = col.generate_source()
+    for kern in meta['kernels'].values():
+        assert kern['lds_bytes'] <= 160*1024
+    assert meta['kernels']['jac']['waves_per_wg'] < 4
