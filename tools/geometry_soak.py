@@ -48,11 +48,18 @@ def variants(count):
     return out
 
 
+#: OPTY_SOAK_LAYOUT=csr / csr+prune / prune: the opt-in output layouts
+LAYOUT = os.environ.get('OPTY_SOAK_LAYOUT', 'coo')
+
+
 def collocator(name, nodes, kw):
     factory, fkw = problems.CONFIGS[name]
     pkw = factory(**dict(fkw, num_nodes=nodes))
     opts = EmitOptions(**kw) if kw is not None else None
-    return opty_amd.ConstraintCollocator(emit_options=opts, **pkw)
+    return opty_amd.ConstraintCollocator(
+        emit_options=opts,
+        jacobian_layout='csr' if LAYOUT.startswith('csr') else 'coo',
+        prune_zeros=LAYOUT.endswith('prune'), **pkw)
 
 
 def main():
@@ -114,8 +121,8 @@ def main():
                 print('MISMATCH', name, kw, what, ec, ej, flush=True)
         col.hip.close()
         done += 1
-    print('geometry soak: %d variants of %d systems, %d mismatches'
-          % (done, len(ref), bad))
+    print('geometry soak (%s layout): %d variants of %d systems, %d '
+          'mismatches' % (LAYOUT, done, len(ref), bad))
     sys.exit(1 if bad else 0)
 
 
