@@ -186,9 +186,20 @@ def ufuncify_matrix(args, expr, const=None, tmp_dir=None, parallel=False,
             table[a] = dag.input('cur', nvec)
             nvec += 1
     low = Lowerer(dag, table)
+    # cse() also pulls out Boolean sub-expressions that several Piecewise
+    # conditions share (``x7 = x1 < 1/2``): those are not values of the DAG,
+    # they are put back where they are used
+    from sympy.logic.boolalg import Boolean
+    bools = {}
     for sym, sub in replacements:
-        low.sym[sym] = low.lower(sub)
-    outputs = [low.lower(e) for e in matrix]    # row-major
+        if bools:
+            sub = sub.xreplace(bools)
+        if isinstance(sub, Boolean):
+            bools[sym] = sub
+        else:
+            low.sym[sym] = low.lower(sub)
+    outputs = [low.lower(e.xreplace(bools) if bools else e)
+               for e in matrix]                 # row-major
     return _MatrixFunction(dag, outputs, nvec, const_positions, len(args),
                            matrix.shape, tmp_dir, show_compile_output,
                            device, emit_options)

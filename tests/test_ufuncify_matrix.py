@@ -296,3 +296,31 @@ def test_multi_arg_closures_10link_match_fused_path():
                     what='multi-arg con vs fused', bound=cb)
     gu.assert_close(jac, col.generate_jacobian_function()(free), 1e-12,
                     what='multi-arg jac vs fused', bound=jb)
+
+
+@pytest.mark.gpu
+def test_cse_pair_with_shared_conditions():
+    """``cse()`` also extracts Boolean sub-expressions that several
+    ``Piecewise`` conditions share (``x0 = a < 1/2``); a ``(replacements,
+    [matrix])`` pair with such a replacement evaluates like the matrix itself
+    (found by tools/matrix_soak.py)."""
+    import sympy as sm
+    import opty_amd
+    a, b = sm.symbols('a, b', real=True)
+    half = sm.Rational(1, 2)
+    mat = sm.Matrix([[sm.Piecewise((a**2, a < half), (a/4, True)),
+                      sm.Piecewise((b, a < half), (b**3, True))],
+                     [sm.Piecewise((a + b, sm.And(a < half, b > -half)),
+                                   (a - b, True)), a*b]])
+    pair = sm.cse(mat)
+    from sympy.logic.boolalg import Boolean
+    assert any(isinstance(sub, Boolean) for _, sub in pair[0])
+    f = opty_amd.ufuncify_matrix((a, b), pair)
+    g = opty_amd.ufuncify_matrix((a, b), mat)
+    rng = np.random.default_rng(2)
+    av, bv = rng.uniform(-1, 1, 130), rng.uniform(-1, 1, 130)
+    r1 = f(np.empty((130, 4)), av, bv)
+    r2 = g(np.empty((130, 4)), av, bv)
+    np.testing.assert_array_equal(r1, r2)
+    want = np.where(av < 0.5, av**2, av/4)
+    np.testing.assert_allclose(r1[:, 0, 0], want, rtol=1e-14)
