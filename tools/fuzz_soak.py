@@ -5,6 +5,7 @@ range of seeds beyond the committed ones.
     python tools/fuzz_soak.py dag 36 200      # DAG interpreter vs oracle (CPU)
     python tools/fuzz_soak.py build 36 200    # prebuild code objects (CPU)
     python tools/fuzz_soak.py hip 36 200      # HIP kernels vs oracle (GPU box)
+    python tools/fuzz_soak.py layouts 0 100   # CSR / pruned layouts (GPU box)
 """
 import os
 import sys
@@ -15,6 +16,41 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, 'tests'))
 
 import numpy as np                                            # noqa: E402
+
+
+def layouts(seed, tf):
+    """Row-sorted, pruned and row-sorted pruned layouts of one random problem
+    (GPU) as sparse matrices against the oracle's triplets."""
+    import scipy.sparse as sp
+    import opty_amd
+    kw, orc, free, c_ref, j_ref, rows, cols = tf._reference(seed)
+    shape = (orc.num_constraints, orc.num_free)
+    ref = sp.coo_matrix((j_ref, (rows, cols)), shape=shape).tocsr()
+    scale = max(float(np.abs(j_ref).max()), 1.0)
+    for layout, prune in (('csr', False), ('coo', True), ('csr', True)):
+        col = opty_amd.ConstraintCollocator(jacobian_layout=layout,
+                                            prune_zeros=prune, **kw)
+        jac = np.array(col.generate_jacobian_function()(free))
+        r, c = col.jacobian_indices()
+        assert r.dtype == np.int64 and len(r) == len(jac)
+        if layout == 'csr':
+            row_ptr, col_idx = col.jacobian_csr_structure()
+            got = sp.csr_matrix((jac, col_idx, row_ptr), shape=shape)
+            assert np.all(np.diff(r) >= 0)
+            np.testing.assert_array_equal(c, col_idx)
+        else:
+            got = sp.coo_matrix((jac, (r, c)), shape=shape).tocsr()
+        if not prune:
+            o = np.lexsort((cols, rows))
+            np.testing.assert_array_equal(rows[o], r)
+            np.testing.assert_array_equal(cols[o], c)
+        diff = abs(got - ref)
+        assert (diff.max() if diff.nnz else 0.0) <= 1e-10*scale, \
+            (seed, layout, prune)
+        con = col.generate_constraint_function()(free)
+        assert np.abs(con - c_ref).max() <= 1e-10*max(
+            1.0, float(np.abs(c_ref).max()))
+        col.hip.close()
 
 
 def main():
@@ -43,6 +79,8 @@ def main():
         try:
             if mode == 'dag':
                 tf.test_expression_dag_against_the_oracle(seed)
+            elif mode == 'layouts':
+                layouts(seed, tf)
             else:
                 tf.test_hip_kernels_against_the_oracle(seed)
         except Exception as err:
