@@ -6,6 +6,7 @@ range of seeds beyond the committed ones.
     python tools/fuzz_soak.py build 36 200    # prebuild code objects (CPU)
     python tools/fuzz_soak.py hip 36 200      # HIP kernels vs oracle (GPU box)
     python tools/fuzz_soak.py layouts 0 100   # CSR / pruned layouts (GPU box)
+    python tools/fuzz_soak.py sharded 0 100   # 2 and 3 node shards (GPU box)
 """
 import os
 import sys
@@ -53,6 +54,46 @@ def layouts(seed, tf):
         col.hip.close()
 
 
+def sharded(seed, tf):
+    """One random problem node-sharded over 2 and 3 ranks (all in this
+    process, on one GPU): the shards' values and index slices, the instance
+    tails and the tail indices, assembled, against the oracle."""
+    import torch
+    from opty_amd.sharded import ShardedCollocator
+    kw, orc, free, c_ref, j_ref, rows, cols = tf._reference(seed)
+    N1, M = orc.N - 1, orc.M
+    for world in (2, 3):
+        if N1 < world:
+            continue
+        con = np.full(len(c_ref), np.nan)
+        jac = np.full(len(j_ref), np.nan)
+        r_all = np.full(len(rows), -1, dtype=np.int64)
+        c_all = np.full(len(cols), -1, dtype=np.int64)
+        con2d = con[:M*N1].reshape(M, N1)
+        for rank in range(world):
+            sh = ShardedCollocator(rank=rank, world_size=world, **kw)
+            f = torch.from_numpy(free).cuda()
+            c, j = sh.evaluate(f)
+            torch.cuda.synchronize()
+            con2d[:, sh.a:sh.b] = c.cpu().numpy()
+            jac[sh.a*sh.P:sh.b*sh.P] = j.cpu().numpy()
+            r, cc = sh.jacobian_indices_local()
+            r_all[sh.a*sh.P:sh.b*sh.P] = r
+            c_all[sh.a*sh.P:sh.b*sh.P] = cc
+            if rank == world - 1 and sh.o:
+                ct, jt = sh.evaluate_instance()
+                torch.cuda.synchronize()
+                con[M*N1:] = ct.cpu().numpy()
+                jac[N1*sh.P:] = jt.cpu().numpy()
+                ri, ci = sh.instance_indices()
+                r_all[N1*sh.P:] = ri
+                c_all[N1*sh.P:] = ci
+            sh.collocator.hip.close()
+        tf._check('sharded', seed, orc, con, jac, c_ref, j_ref)
+        np.testing.assert_array_equal(r_all, rows)
+        np.testing.assert_array_equal(c_all, cols)
+
+
 def main():
     mode, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     import opty_amd
@@ -81,6 +122,8 @@ def main():
                 tf.test_expression_dag_against_the_oracle(seed)
             elif mode == 'layouts':
                 layouts(seed, tf)
+            elif mode == 'sharded':
+                sharded(seed, tf)
             else:
                 tf.test_hip_kernels_against_the_oracle(seed)
         except Exception as err:
