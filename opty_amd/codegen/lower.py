@@ -38,6 +38,81 @@ _RECIPROCAL_FUNCS = {sm.sec: 'cos', sm.csc: 'sin', sm.sech: 'cosh',
                      sm.csch: 'sinh'}
 
 
+def _c99_rewrites():
+    """``{function name: target function}`` of the C99 printer's "simple
+    rewrite to a supported function" table (``CodePrinter.
+    _rewriteable_functions``; the reference's printer inherits it,
+    ``opty/utils.py:61``)."""
+    try:
+        from sympy.printing.c import C99CodePrinter
+        table = C99CodePrinter._rewriteable_functions
+    except (ImportError, AttributeError):       # pragma: no cover
+        return {}
+    out = {}
+    for name, (target, _) in table.items():
+        fn = getattr(sm, target, None)
+        if fn is not None:
+            out[name] = fn
+    return out
+
+
+_C99_REWRITES = _c99_rewrites()
+
+
+def _printer_expansion(e):
+    """The expression the reference's code printer prints *in place of* an
+    applied function that is not in its function table, or None.
+
+    The reference prints every sub-expression with a ``C99CodePrinter``
+    (``opty/utils.py:61-79``, ``:751-757``), whose dispatch accepts far more
+    than the table of C math functions:
+
+    1. an object's own printer hook (``_ccode``) wins -- the musculotendon
+       curves of ``sympy.physics.biomechanics`` print their defining
+       expression, ``self.doit(deep=False, evaluate=False)``;
+    2. a function with a numeric implementation attached as a ``Lambda``
+       (``implemented_function``) is inlined;
+    3. functions in the printer's rewrite table (``acot``, ``asec``,
+       ``binomial``, ``frac``, ``SingularityFunction`` ...) are rewritten in
+       terms of a printable one.
+
+    The HIP backend lowers that same expansion into the DAG; derivatives then
+    come from forward mode over the expansion, where the reference
+    differentiates symbolically through ``fdiff`` -- equal functions.  An
+    undefined function (``r(x)`` that is not a known trajectory) has no
+    expansion, here as there.
+    """
+    if not isinstance(e, sm.Function) or \
+            isinstance(e, sm.core.function.AppliedUndef) and \
+            not hasattr(e, '_imp_'):
+        return None
+    cands = []
+    if hasattr(e, '_ccode') or hasattr(e, '_print_code'):
+        for kw in (dict(deep=False, evaluate=False), dict(deep=False)):
+            try:
+                cands.append(e.doit(**kw))
+                break
+            except TypeError:
+                continue
+    imp = getattr(e, '_imp_', None)
+    if isinstance(imp, sm.Lambda):
+        cands.append(imp(*e.args))
+    target = _C99_REWRITES.get(e.func.__name__)
+    if target is not None:
+        cands.append(e.rewrite(target))
+    if not cands:
+        # last resort, also what ``_print_Function`` falls back on for
+        # subclasses that evaluate lazily
+        try:
+            cands.append(e.doit(deep=False))
+        except Exception:                       # noqa: BLE001
+            pass
+    for x in cands:
+        if isinstance(x, sm.Basic) and x != e and not x.has(e.func):
+            return x
+    return None
+
+
 class Lowerer(object):
     """Lowers SymPy expressions over a fixed symbol table into one DAG."""
 
@@ -151,6 +226,11 @@ class Lowerer(object):
             for expr, cond in reversed(e.args):
                 acc = self._select(cond, self.lower(expr), acc)
             return acc
+        if isinstance(e, sm.UnevaluatedExpr):
+            return m[e.args[0]]
+        expansion = _printer_expansion(e)
+        if expansion is not None:
+            return self.lower(expansion)
         raise LoweringError('cannot lower %s (%s) to the HIP backend'
                             % (f, e))
 

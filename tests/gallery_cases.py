@@ -1,0 +1,66 @@
+"""The problems of the reference's example gallery as test inputs.
+
+``tests/golden/gallery_<name>.npz`` (written by
+``tests/golden/_gen/gallery_capture.py`` in the build container) holds, per
+gallery script, the arguments the script constructs its ``Problem`` with --
+as data: SymPy expression tables (:mod:`sympy_codec`), parameter values and
+known-trajectory arrays -- and what the REAL reference (compiled Cython
+backend) returned for ``constraints(free)``, ``jacobian(free)`` and
+``jacobian_indices()`` at the recorded ``free`` vector.  :func:`load` turns the
+data back into keyword arguments that :class:`opty_amd.ConstraintCollocator`
+(and the oracle) accept.
+
+Known trajectories that a script supplies as functions of ``free``
+(``plot_hilly_race.py``) are recorded as the arrays they return at the
+fixture's ``free`` -- the reference evaluates them once per call and does not
+differentiate through them (``opty/direct_collocation.py:2916-2917``).
+"""
+import json
+import os
+
+import numpy as np
+
+import sympy_codec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+with open(os.path.join(GOLDEN, 'GALLERY.json')) as _f:
+    MANIFEST = json.load(_f)
+
+NAMES = sorted(MANIFEST)
+FULL = [k for k in NAMES if MANIFEST[k]['kind'] == 'full']
+SAMPLED = [k for k in NAMES if MANIFEST[k]['kind'] == 'sampled']
+
+
+def load(name):
+    """-> ``(meta, arrays, kwargs)``."""
+    meta = MANIFEST[name]
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    lay = meta['layout']
+    objs = sympy_codec.decode(json.loads(str(z['problem'])))
+    k = 0
+    eom = objs[k]
+    k += 1
+    states = tuple(objs[k:k + lay['num_states']])
+    k += lay['num_states']
+    par_syms = objs[k:k + lay['num_par']]
+    k += lay['num_par']
+    traj_syms = objs[k:k + lay['num_traj']]
+    k += lay['num_traj']
+    inst = tuple(objs[k:k + lay['num_inst']])
+    k += lay['num_inst']
+    interval_sym, time_sym = objs[k], objs[k + 1]
+    kwargs = dict(
+        equations_of_motion=eom, state_symbols=states,
+        num_collocation_nodes=meta['N'],
+        node_time_interval=(interval_sym if lay['interval_is_symbol']
+                            else float(z['interval'][0])),
+        known_parameter_map=dict(zip(par_syms,
+                                     (float(v) for v in z['par_values']))),
+        known_trajectory_map=dict(zip(traj_syms,
+                                      (np.array(v) for v in
+                                       z['traj_values']))),
+        instance_constraints=inst if lay['num_inst'] else None,
+        time_symbol=time_sym if lay['has_time_symbol'] else None,
+        integration_method=meta['method'])
+    return meta, z, kwargs
