@@ -421,6 +421,31 @@ def gait_like_pendulum(num_links=24, num_nodes=50000, method='backward euler',
                 integration_method=method)
 
 
+def gallery_problem(name='gallery_one_legged_time_trial', num_nodes=None):
+    """A problem of the reference's example gallery, from the inputs recorded
+    in ``tests/golden/<name>.npz`` (``tests/golden/_gen/gallery_capture.py``),
+    optionally on another node count (``tests/gallery_cases.py:rescale``).
+
+    ``gallery_one_legged_time_trial``: ``examples-gallery/advanced/
+    plot_one_legged_time_trial.py`` -- a four-bar leg + crank driven by four
+    De Groote (2016) musculotendon actuators (``sympy.physics.biomechanics``):
+    12 states (4 coordinates, 4 speeds, 4 activations), 4 excitations as
+    unknown inputs, variable duration, 13 instance constraints; the one
+    musculoskeletal model of the gallery that builds with SymPy alone.
+    """
+    import os
+    import sys
+    tests = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), 'tests')
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+    import gallery_cases
+    _, _, kw = gallery_cases.load(name)
+    if num_nodes is not None:
+        kw = gallery_cases.rescale(kw, num_nodes)
+    return kw
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -483,6 +508,9 @@ CONFIGS = {
                                   'method': 'midpoint'}),
     'config5_gaitlike_24link': (gait_like_pendulum, {}),
     'config5_gaitlike_24link_small': (gait_like_pendulum, {'num_nodes': 6}),
+    # a real muscle-driven DAE with a reference golden (config-5 class)
+    'one_legged_small': (gallery_problem, {'num_nodes': 43}),
+    'config5_one_legged': (gallery_problem, {'num_nodes': 50000}),
 }
 
 

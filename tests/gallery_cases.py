@@ -64,3 +64,41 @@ def load(name):
         time_symbol=time_sym if lay['has_time_symbol'] else None,
         integration_method=meta['method'])
     return meta, z, kwargs
+
+
+def rescale(kwargs, num_nodes):
+    """The same problem on ``num_nodes`` collocation nodes (full-size bench /
+    parity workloads from a gallery problem): the duration is kept for a
+    fixed interval, instance-constraint times ``k*h`` of a variable-duration
+    problem keep their relative position (``k -> round(k (N'-1)/(N-1))``, so
+    ``(N-1)*h`` stays the last node), known trajectories are interpolated
+    onto the new grid."""
+    import sympy as sm
+    kw = dict(kwargs)
+    old = kw['num_collocation_nodes']
+    if num_nodes == old:
+        return kw
+    kw['num_collocation_nodes'] = int(num_nodes)
+    h = kw['node_time_interval']
+    if isinstance(h, sm.Symbol):
+        def move(con):
+            rep = {}
+            for f in con.atoms(sm.Function):
+                if not isinstance(f, sm.core.function.AppliedUndef):
+                    continue
+                k = f.args[0]/h
+                if k.is_Number and k != 0:
+                    rep[f] = f.func(int(round(float(k)*(num_nodes - 1) /
+                                              (old - 1)))*h)
+            return con.xreplace(rep)
+        if kw['instance_constraints'] is not None:
+            kw['instance_constraints'] = tuple(
+                move(sm.sympify(c)) for c in kw['instance_constraints'])
+    else:
+        kw['node_time_interval'] = float(h)*(old - 1)/(num_nodes - 1)
+    grid_old = np.linspace(0.0, 1.0, old)
+    grid_new = np.linspace(0.0, 1.0, num_nodes)
+    kw['known_trajectory_map'] = {
+        f: np.interp(grid_new, grid_old, v)
+        for f, v in kw['known_trajectory_map'].items()}
+    return kw

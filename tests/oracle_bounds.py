@@ -84,6 +84,8 @@ class _Evaluator(object):
             for p in parts[1:]:
                 v = f(v, p[0])
             return v, sum(p[1] for p in parts)
+        if isinstance(e, sm.UnevaluatedExpr):
+            return self(e.args[0])
         if isinstance(e, sm.Function):
             args = [self(a) for a in e.args]
             fn = sm.lambdify(sm.symbols('x0:%d' % len(args)),
