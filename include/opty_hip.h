@@ -176,8 +176,11 @@ int opty_hip_eval_con_jac(opty_hip_problem *p, const double *free, double *con,
  * vector of the previous call and the invariant entries it holds are still
  * valid (they are re-sent after opty_hip_set_known_parameters /
  * opty_hip_set_interval).  The caller must not write into `jac` between
- * calls.  Node-major layout only; without varying entries set it is
- * opty_hip_eval_jac. */
+ * calls, and passes `fresh` != 0 on the FIRST call with an allocation (and
+ * whenever it may have written into it): the library compares addresses only
+ * as a second line of defence -- an allocator hands a freed block out again at
+ * the same address, so address identity is not a validity token.  Node-major
+ * layout only; without varying entries set it is opty_hip_eval_jac. */
 int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
                                  int32_t count);
 /* Block entries that are the SAME expression as an earlier varying entry (a
@@ -190,18 +193,23 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
 int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
                               const int32_t *src, int32_t count);
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
-                                 double *jac);
+                                 double *jac, int32_t fresh);
+/* Largest fraction of a block's stored entries for which only the varying
+ * ones are moved (beyond it whole blocks are copied and no entry copies are
+ * applied): 0.8, or OPTY_HIP_PACK_RATIO. */
+double opty_hip_pack_ratio(void);
 /* The same for one node shard of a problem evaluated by several GPUs: the
  * blocks of the constraint nodes [node_begin, node_end), as
  * opty_hip_eval_shard left them in device memory (d_jac_shard), go into the
  * slice [node_begin*P, node_end*P) of the dense HOST vector of the GLOBAL
  * problem (host_jac: the shared page-locked vector every rank copies its
  * shard into, SURVEY.md 8(e) "direct-to-host") -- all of them the first
- * time, later only the varying entries.  Synchronous; runs on the handle's
+ * time (and whenever `fresh` != 0: a new mapping of the shared vector, see
+ * above), later only the varying entries.  Synchronous; runs on the handle's
  * stream behind the evaluation. */
 int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
                                double *host_jac, int64_t node_begin,
-                               int64_t node_end);
+                               int64_t node_end, int32_t fresh);
 /* Host threads of the scatter pool (per process; 0 = the default:
  * OPTY_HIP_HOST_THREADS, or min(16, hardware threads / 4 / LOCAL_WORLD_SIZE)
  * -- the ranks of a node share the cores of the NUMA node that holds the one
@@ -209,7 +217,11 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
  * LOCAL_RANK deciding which).  The workers run on the cores of
  * the NUMA node that holds the caller's dense vector (get_mempolicy);
  * OPTY_HIP_HOST_NUMA=<node> overrides, =off leaves them where the creating
- * thread may run. */
+ * thread may run.  The workers never leave the affinity mask of the thread
+ * that created the pool (taskset / cpuset / an OpenMP binding are honoured,
+ * and the pool has at most as many workers as that mask has CPUs);
+ * OPTY_HIP_HOST_AFFINITY=wide lifts that for applications whose binding pins
+ * only the calling thread. */
 int opty_hip_set_host_threads(int32_t count);
 int opty_hip_host_threads(void);
 /* NUMA node that holds the first page of a host allocation (-1: unknown). */

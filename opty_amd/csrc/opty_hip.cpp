@@ -263,6 +263,10 @@ public:
         cores_.clear();
         for (int c = 0; c < CPU_SETSIZE; ++c) {
             if (!CPU_ISSET(c, &set)) continue;
+            if (!CPU_ISSET(c, &allowed_)) {     // outside the process's mask
+                CPU_CLR(c, &set);
+                continue;
+            }
             snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/"
                      "topology/thread_siblings_list", c);
             int first = c;
@@ -270,8 +274,10 @@ public:
                 if (fscanf(g, "%d", &first) != 1) first = c;
                 fclose(g);
             }
-            if (first == c) cores_.push_back(c);
+            if (first == c || !CPU_ISSET(first, &allowed_))
+                cores_.push_back(c);
         }
+        if (CPU_COUNT(&set) == 0) return;   // none of that node's CPUs is ours
         node_ = node;
         cpus_ = set;
         have_cpus_ = true;
@@ -282,6 +288,7 @@ public:
         std::lock_guard<std::recursive_mutex> lk(busy_);
         stop();
         n = std::max(1, std::min(n, 256));
+        if (!widen_) n = std::min(n, std::max(1, CPU_COUNT(&allowed_)));
         quit_ = false;
         // the epoch the new workers have seen is fixed HERE, by the thread
         // that also starts the jobs: a worker that read it on its own could
@@ -314,7 +321,24 @@ public:
     }
 
 private:
-    ScatterPool() : pid_(getpid()) { resize(default_threads()); }
+    ScatterPool() : pid_(getpid()) {
+        // The CPUs this pool may use: the affinity mask of the thread that
+        // creates it (a taskset / cpuset / OpenMP binding the host
+        // application chose is honoured: workers never run outside it and
+        // there are never more workers than CPUs in it).
+        // OPTY_HIP_HOST_AFFINITY=wide restores the round-3 behaviour for
+        // applications whose binding pins only the calling thread
+        // (OMP_PROC_BIND pins the thread that loads this library to one
+        // core): all CPUs of the machine.
+        CPU_ZERO(&allowed_);
+        const char *mode = getenv("OPTY_HIP_HOST_AFFINITY");
+        const bool wide = mode && strcmp(mode, "wide") == 0;
+        if (wide || sched_getaffinity(0, sizeof allowed_, &allowed_) != 0 ||
+            CPU_COUNT(&allowed_) == 0)
+            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &allowed_);
+        widen_ = wide;
+        resize(default_threads());
+    }
 
     void stop() {
         {
@@ -347,12 +371,10 @@ private:
             (void)sched_setaffinity(0, sizeof one, &one);
         } else if (have_cpus_) {
             (void)sched_setaffinity(0, sizeof cpus_, &cpus_);
-        } else if (sched_getaffinity(0, sizeof mask, &mask) == 0 &&
+        } else if (widen_ &&
+                   sched_getaffinity(0, sizeof mask, &mask) == 0 &&
                    CPU_COUNT(&mask) < T) {
-            cpu_set_t wide;
-            CPU_ZERO(&wide);
-            for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &wide);
-            (void)sched_setaffinity(0, sizeof wide, &wide);
+            (void)sched_setaffinity(0, sizeof allowed_, &allowed_);
         }
         for (;;) {
             {
@@ -363,8 +385,15 @@ private:
             }
             const Job j = job_;
             for (int c = 0; c < j.chunks; ++c) {
-                while (ready_.load(std::memory_order_acquire) <= c)
-                    __builtin_ia32_pause();
+                // a chunk lands every ~0.3 ms: spin briefly, then give the
+                // core away between polls
+                for (unsigned spins = 0;
+                     ready_.load(std::memory_order_acquire) <= c; ++spins) {
+                    if (spins < 4096) cpu_relax();
+                    else if (spins < 4096 + 64) std::this_thread::yield();
+                    else std::this_thread::sleep_for(
+                        std::chrono::microseconds(20));
+                }
                 const long long a = j.nodes*c/j.chunks,
                                 b = j.nodes*(c + 1)/j.chunks;
                 const long long i0 = a + (b - a)*t/T,
@@ -385,7 +414,19 @@ private:
         }
     }
 
+    static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        __asm__ __volatile__("yield");
+#else
+        std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+    }
+
     pid_t pid_;
+    cpu_set_t allowed_;          // CPUs the workers may run on
+    bool widen_ = false;         // OPTY_HIP_HOST_AFFINITY=wide
     int node_ = -1;
     bool have_cpus_ = false;
     cpu_set_t cpus_;
@@ -1731,8 +1772,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     return rc;
 }
 
-// nothing to gain from packing: no table, or most of the block varies
-static bool packing_pays(const opty_hip_problem *p) {
+static double pack_ratio() {
     static const double ratio = [] {
         const char *env = getenv("OPTY_HIP_PACK_RATIO");
         const double r = env ? atof(env) : 0.0;
@@ -1741,12 +1781,19 @@ static bool packing_pays(const opty_hip_problem *p) {
         // host scatter cost less than the bytes they save well beyond half
         return r > 0.0 && r <= 1.0 ? r : 0.8;
     }();
-    return p->d.layout == OPTY_HIP_LAYOUT_COO && p->d_var != nullptr &&
-           (double)p->var_entries.size() <= ratio*(double)p->P();
+    return ratio;
 }
 
+// nothing to gain from packing: no table, or most of the block varies
+static bool packing_pays(const opty_hip_problem *p) {
+    return p->d.layout == OPTY_HIP_LAYOUT_COO && p->d_var != nullptr &&
+           (double)p->var_entries.size() <= pack_ratio()*(double)p->P();
+}
+
+double opty_hip_pack_ratio(void) { return pack_ratio(); }
+
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
-                                 double *jac) {
+                                 double *jac, int32_t fresh) {
     if (!p) return fail("null handle");
     if (!free_ || !jac) return fail("null buffer");
     if (int rc = use_device(p)) return rc;
@@ -1760,8 +1807,11 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
                              p->d_jac, whole(p), true))
         return rc;
-    const bool full = !p->static_valid || p->static_host != jac ||
-                      !packing_pays(p);
+    // `fresh`: the caller's word that `jac` does not hold this handle's
+    // invariant entries.  The address alone proves nothing -- a freed block
+    // can come back from the allocator at the same address.
+    const bool full = fresh != 0 || !p->static_valid ||
+                      p->static_host != jac || !packing_pays(p);
     if (p->d.nnz_inst > 0)
         HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
                                p->d.nnz_inst*sizeof(double),
@@ -1778,7 +1828,7 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
 
 int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
                                double *host_jac, int64_t node_begin,
-                               int64_t node_end) {
+                               int64_t node_end, int32_t fresh) {
     if (!p) return fail("null handle");
     if (!d_jac_shard || !host_jac) return fail("null buffer");
     if (node_begin < 0 || node_end < node_begin ||
@@ -1790,7 +1840,8 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
         return fail("the CSR layout is not node-sharded");
     if (int rc = use_device(p)) return rc;
     if (int rc = order_streams(p)) return rc;
-    const bool full = !p->shard_valid || p->shard_host != host_jac ||
+    const bool full = fresh != 0 || !p->shard_valid ||
+                      p->shard_host != host_jac ||
                       p->shard_begin != node_begin ||
                       p->shard_end != node_end || !packing_pays(p);
     if (int rc = move_blocks_to_host(p, d_jac_shard,

@@ -557,7 +557,17 @@ class ConstraintCollocator(object):
         hsaco = hb.compile_module(source, self.tmp_dir,
                                   self.show_compile_output,
                                   opt_level=opt_level)
+        self._built_source = source
         if self._emit_options is not None:
+            # the caller fixed the geometry: it is built as asked, but never
+            # silently -- this is the build class that returned wrong values
+            spills = hb.vgpr_spills(hsaco)
+            if spills:
+                logger.warning(
+                    'emit_options give kernels that spill vector registers '
+                    'to scratch memory (%s); such builds have returned wrong '
+                    'values (DESIGN.md 4.1): drop emit_options, or verify '
+                    'with ConstraintCollocator.cross_check()', spills)
             return hsaco, meta
         best = (hsaco, meta, hb.vgpr_spills(hsaco), (source, meta))
         geo = meta['geometry']
@@ -620,8 +630,135 @@ class ConstraintCollocator(object):
                            best[2], self.num_states, self._program.P,
                            self._launch_blocks(),
                            ' '.join(hb.SAFE_SCHEDULER_FLAGS))
+            self._built_source = source
             return hsaco, meta
+        self._built_source = best[3][0]
         return best[0], best[1]
+
+    def prebuild(self):
+        """Builds everything :meth:`_ensure_hip` will want, without a device:
+        the code object and, for kernels at the register limit, the ``-O1``
+        twin that :meth:`_verify_build` compares it with.  Returns ``(hsaco,
+        meta)``."""
+        hsaco, meta = self._build_code_object()
+        if hb.high_pressure_kernels(hsaco):
+            hb.compile_module(self._built_source, self.tmp_dir,
+                              self.show_compile_output, opt_level='-O1')
+        return hsaco, meta
+
+    #: nodes the automatic check below evaluates (``OPTY_CROSS_CHECK=off``
+    #: disables it)
+    _VERIFY_NODES = 131
+
+    def _verify_build(self, hsaco, meta):
+        """Holds a build whose kernels sit at the edge of the register file
+        (``hip_backend.high_pressure_kernels``: >= 480 VGPRs or spilled
+        SGPRs) to an ``-O1`` twin of the SAME generated source before the
+        handle is handed out; raises :class:`hip_backend.HipBackendError` on
+        disagreement.
+
+        Why: the wrong, run-to-run different values of round 3 came from
+        ``-O2`` schedules of exactly such kernels (the pre-RA scheduler's
+        high-register-pressure stage); "no vector spills" is a
+        symptom fence, this is the check itself.  Both code objects evaluate
+        the first ``_VERIFY_NODES`` nodes of the problem (two full waves and a
+        ragged one; the kernels do not depend on N, the wrong builds were
+        wrong at every node) -- constraints, Jacobian and the fused launch --
+        on seeded values.  The verdict is remembered next to the code object
+        (``<hsaco>.crosscheck.json``), the twin is cached by source hash like
+        every build (``__graft_entry__.build`` prebuilds it)."""
+        import json
+        import os
+        if os.environ.get('OPTY_CROSS_CHECK', '').lower() == 'off':
+            return None
+        hot = hb.high_pressure_kernels(hsaco)
+        if not hot:
+            return None
+        side = hsaco + '.crosscheck.json'
+        try:
+            with open(side) as f:
+                verdict = json.load(f)
+            if verdict.get('ok') is True:
+                return verdict
+        except (OSError, ValueError):
+            pass
+        logger.info('kernels %s are at the register limit: checking the '
+                    'build against its -O1 twin', hot)
+        twin = hb.compile_module(self._built_source, self.tmp_dir,
+                                 self.show_compile_output, opt_level='-O1')
+        worst = self._compare_builds(meta, hsaco, twin)
+        verdict = dict(ok=bool(worst <= self._VERIFY_RTOL), worst=worst,
+                       kernels={k: list(v) for k, v in hot.items()},
+                       twin=os.path.basename(twin))
+        if not verdict['ok']:
+            raise hb.HipBackendError(
+                'the optimised build of this problem\'s kernels (%s: %s) '
+                'disagrees with its -O1 twin by %.3g relative: a compiler '
+                'fault (DESIGN.md 4.1).  Rebuild with OPTY_HIPCC_OPT=-O1 or '
+                'other emit_options.' % (os.path.basename(hsaco), hot, worst))
+        try:
+            tmp = side + '.%d.tmp' % os.getpid()
+            with open(tmp, 'w') as f:
+                json.dump(verdict, f)
+            os.replace(tmp, side)
+        except OSError:
+            pass
+        return verdict
+
+    _VERIFY_RTOL = 1e-9
+
+    def _compare_builds(self, meta, hsaco_a, hsaco_b, seed=7):
+        """Largest disagreement (relative to the largest value of each
+        vector) of two code objects of this problem's module on the first
+        ``_VERIFY_NODES`` nodes: separate and fused launches, host buffers,
+        no instance tails (they are scalar code)."""
+        N = min(self.num_collocation_nodes, self._VERIFY_NODES)
+        n, q = self.num_states, self.num_unknown_input_trajectories
+        rng = np.random.default_rng(seed)
+        free = rng.uniform(-1.0, 1.0, (n + q)*N + self.num_unknown_parameters
+                           + int(self._variable_duration))
+        if self._variable_duration:
+            free[-1] = 0.01
+        desc = dict(self._descriptor(meta), N=N, num_inst=0, nnz_inst=0,
+                    num_inst_atoms=0, inst_folded=0)
+        known = None
+        if self.num_known_input_trajectories:
+            known = np.ascontiguousarray(self._known_trajectory_array(
+                np.ones(self.num_free))[:, :N])
+        outs = []
+        for hsaco in (hsaco_a, hsaco_b):
+            h = hb.HipProblem(desc, hsaco)
+            try:
+                if not self._variable_duration:
+                    h.set_interval(self.node_time_interval)
+                if self.num_known_parameters:
+                    h.set_known_parameters(np.array(
+                        [float(self.known_parameter_map[p])
+                         for p in self.known_parameters]))
+                if known is not None:
+                    h.set_known_trajectories(known)
+                if self._program.pruned or self._jacobian_layout == 'csr':
+                    h.set_block_pattern(self._program.pattern)
+                vecs = []
+                con = np.empty(self.num_eom*(N - 1))
+                jac = np.empty(h.nnz)
+                h.eval_con(free, con, hb.HOST)
+                h.eval_jac(free, jac, hb.HOST)
+                vecs += [con.copy(), jac.copy()]
+                h.eval_con_jac(free, con, jac, hb.HOST)
+                vecs += [con, jac]
+                outs.append(vecs)
+            finally:
+                h.close()
+        worst = 0.0
+        for x, y in zip(*outs):
+            scale = max(float(np.abs(x).max()), 1e-300) if x.size else 1.0
+            if x.size:
+                d = np.abs(x - y)
+                worst = max(worst, float(d.max())/scale
+                            if np.isfinite(d).all() else np.inf)
+        return worst
+
 
     def tune_launch(self, **kwargs):
         """Times the neighbouring launch geometries of this problem on the
@@ -633,7 +770,10 @@ class ConstraintCollocator(object):
         if self._hip is not None:
             self._hip.close()
         self._hip = None
-        self._emit_options = None
+        if kwargs.get('save', True):
+            # the recorded plan is what the next build looks up; options the
+            # caller fixed stay in force when nothing was recorded
+            self._emit_options = None
         return entry
 
     def cross_check(self, free=None, window=4096, opt_level='-O1'):
@@ -654,7 +794,10 @@ class ConstraintCollocator(object):
         system takes a minute or two to compile).  Needs ``torch``."""
         import torch
         hip = self._ensure_hip()
-        hsaco, meta = self._build_code_object(opt_level=opt_level)
+        meta = self._kernel_meta
+        hsaco = hb.compile_module(self._built_source, self.tmp_dir,
+                                  self.show_compile_output,
+                                  opt_level=opt_level)
         twin = hb.HipProblem(self._descriptor(meta), hsaco)
         try:
             self._install_tables(twin)
@@ -743,6 +886,7 @@ class ConstraintCollocator(object):
             return self._hip
         logger.info('Compiling the HIP constraint/Jacobian kernels.')
         hsaco, meta = self._build_code_object()
+        self._build_verdict = self._verify_build(hsaco, meta)
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
         self._install_tables(hip)
         self._kernel_meta = meta
@@ -998,11 +1142,17 @@ class ConstraintCollocator(object):
                       hip.nnz >= self._PERSISTENT_MIN_NNZ and
                       os.environ.get('OPTY_HOST_DENSE') != '1')
 
+        # `result` is a new allocation: whatever the handle last filled at
+        # this address (a dropped closure's buffer can come back from the
+        # allocator) is not in it
+        state = {'fresh': True}
+
         def jacobian(free):
             free = self._host_free(free)
             self._sync_known(hip, free)
             if persistent:
-                hip.eval_jac_persistent(free, result)
+                hip.eval_jac_persistent(free, result, state['fresh'])
+                state['fresh'] = False
             else:
                 hip.eval_jac(free, result, hb.HOST)
             return result

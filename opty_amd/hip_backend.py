@@ -152,29 +152,45 @@ _RESOURCE_KEYS = ('.vgpr_count', '.agpr_count', '.sgpr_count',
 def kernel_resources(hsaco_path):
     """``{kernel: {'.vgpr_count': ..., '.vgpr_spill_count': ...,
     '.private_segment_fixed_size': ..., ...}}`` from the AMDGPU metadata note
-    of a code object built by :func:`compile_module`."""
+    of a code object built by :func:`compile_module`.  Raises
+    :class:`HipBackendError` when the tools fail or the note has no kernel
+    records -- a guard built on this must not pass because nothing was
+    read."""
     import re
     import tempfile
     llvm = os.path.join(os.path.dirname(os.path.dirname(
         os.path.realpath(_hipcc()))), 'lib', 'llvm', 'bin')
     if not os.path.isdir(llvm):
         llvm = '/opt/rocm/lib/llvm/bin'
-    with tempfile.NamedTemporaryFile(suffix='.elf') as elf:
-        # `hipcc --genco` writes an offload bundle: take the gfx950 ELF out
-        subprocess.run([os.path.join(llvm, 'clang-offload-bundler'),
-                        '--unbundle', '--type=o', '--input=' + hsaco_path,
-                        '--targets=hipv4-amdgcn-amd-amdhsa--' + ARCH,
-                        '--output=' + elf.name], check=True,
-                       capture_output=True)
-        txt = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes',
-                              elf.name], capture_output=True,
-                             text=True).stdout
+    try:
+        with tempfile.NamedTemporaryFile(suffix='.elf') as elf:
+            # `hipcc --genco` writes an offload bundle: take the gfx950 ELF
+            # out
+            subprocess.run([os.path.join(llvm, 'clang-offload-bundler'),
+                            '--unbundle', '--type=o',
+                            '--input=' + hsaco_path,
+                            '--targets=hipv4-amdgcn-amd-amdhsa--' + ARCH,
+                            '--output=' + elf.name], check=True,
+                           capture_output=True)
+            txt = subprocess.run([os.path.join(llvm, 'llvm-readelf'),
+                                  '--notes', elf.name], capture_output=True,
+                                 text=True, check=True).stdout
+    except (OSError, subprocess.CalledProcessError) as err:
+        raise HipBackendError('cannot read the kernel metadata of %s: %s'
+                              % (hsaco_path, err)) from err
     out = {}
     for blk in txt.split('- .agpr_count')[1:]:
         blk = '.agpr_count' + blk
-        name = re.search(r'\.name:\s+(\S+)', blk).group(1)
-        out[name] = {k: int(re.search(re.escape(k) + r':\s+(\d+)', blk)
-                            .group(1)) for k in _RESOURCE_KEYS}
+        name = re.search(r'\.name:\s+(\S+)', blk)
+        vals = {k: re.search(re.escape(k) + r':\s+(\d+)', blk)
+                for k in _RESOURCE_KEYS}
+        if name is None or any(v is None for v in vals.values()):
+            raise HipBackendError('unexpected kernel metadata in %s:\n%s'
+                                  % (hsaco_path, blk[:400]))
+        out[name.group(1)] = {k: int(v.group(1)) for k, v in vals.items()}
+    if not out:
+        raise HipBackendError('no kernel records in the metadata of %s'
+                              % hsaco_path)
     return out
 
 
@@ -185,11 +201,55 @@ def vgpr_spills(hsaco_path, kernels=('opty_con', 'opty_jac', 'opty_conjac')):
     code objects whose results were wrong and differed from run to run (the
     24-link stand-in with 19 strips: 32 spilled VGPRs, 100 B of scratch);
     every such case seen so far spilled vector registers, none of the
-    spill-free builds misbehaved."""
-    res = kernel_resources(hsaco_path)
+    spill-free builds misbehaved.
+
+    The verdict (all resource counts of the named kernels) is cached next to
+    the code object (``<hsaco>.resources.json``), so a cache hit of
+    :func:`compile_module` costs no subprocess.  A code object that holds
+    NONE of the named kernels is an error, not "no spills"."""
+    res = cached_kernel_resources(hsaco_path)
+    if not any(k in res for k in kernels):
+        raise HipBackendError('%s holds none of the kernels %s (found %s)'
+                              % (hsaco_path, list(kernels), sorted(res)))
     return {k: res[k]['.vgpr_spill_count'] for k in kernels
             if k in res and (res[k]['.vgpr_spill_count'] > 0 or
                              res[k]['.private_segment_fixed_size'] > 0)}
+
+
+def cached_kernel_resources(hsaco_path):
+    """:func:`kernel_resources`, remembered in ``<hsaco>.resources.json``."""
+    import json
+    side = hsaco_path + '.resources.json'
+    try:
+        if os.path.getmtime(side) >= os.path.getmtime(hsaco_path):
+            with open(side) as f:
+                res = json.load(f)
+            if isinstance(res, dict) and res:
+                return res
+    except (OSError, ValueError):
+        pass
+    res = kernel_resources(hsaco_path)
+    try:
+        tmp = side + '.%d.tmp' % os.getpid()
+        with open(tmp, 'w') as f:
+            json.dump(res, f)
+        os.replace(tmp, side)
+    except OSError:                         # read-only cache: recompute later
+        pass
+    return res
+
+
+def high_pressure_kernels(hsaco_path, vgpr_limit=480,
+                          kernels=('opty_con', 'opty_jac', 'opty_conjac')):
+    """Kernels at the edge of the register file: ``>= vgpr_limit`` vector
+    registers or any spilled scalar registers -- the builds whose schedules
+    go through the compiler's high-register-pressure stages.
+    ``{kernel: (vgprs, sgpr spills)}``."""
+    res = cached_kernel_resources(hsaco_path)
+    return {k: (res[k]['.vgpr_count'], res[k]['.sgpr_spill_count'])
+            for k in kernels if k in res and
+            (res[k]['.vgpr_count'] >= vgpr_limit or
+             res[k]['.sgpr_spill_count'] > 0)}
 
 
 class _Desc(ctypes.Structure):
@@ -253,9 +313,11 @@ _SIGNATURES = {
     'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_set_varying_entries': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
     'opty_hip_set_entry_copies': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
-    'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P]),
+    'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P,
+                                                    ctypes.c_int32]),
+    'opty_hip_pack_ratio': (ctypes.c_double, []),
     'opty_hip_shard_jac_to_host': (ctypes.c_int, [
-        _P, _P, _P, ctypes.c_int64, ctypes.c_int64]),
+        _P, _P, _P, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32]),
     'opty_hip_set_host_threads': (ctypes.c_int, [ctypes.c_int32]),
     'opty_hip_host_threads': (ctypes.c_int, []),
     'opty_hip_host_numa_node': (ctypes.c_int, [_P]),
@@ -374,6 +436,12 @@ def host_threads():
     return load_library().opty_hip_host_threads()
 
 
+def pack_ratio():
+    """Largest varying fraction of a block for which the host-visible
+    Jacobian moves only the varying entries (``opty_hip_pack_ratio``)."""
+    return float(load_library().opty_hip_pack_ratio())
+
+
 def host_numa_node(array):
     """NUMA node that holds the first page of a NumPy array (-1: unknown)."""
     return load_library().opty_hip_host_numa_node(array.ctypes.data)
@@ -481,18 +549,22 @@ class HipProblem(object):
         _check(self._lib.opty_hip_set_entry_copies(self._h, _ptr(dst),
                                                    _ptr(src), len(dst)))
 
-    def eval_jac_persistent(self, free, jac):
+    def eval_jac_persistent(self, free, jac, fresh):
         """``opty_hip_eval_jac_persistent``: host ``free``, page-locked
-        persistent host ``jac``."""
+        persistent host ``jac``; ``fresh``: ``jac`` is a new allocation (or
+        was written to) since this handle last filled it."""
         _check(self._lib.opty_hip_eval_jac_persistent(
-            self._h, _ptr(free), _ptr(jac)))
+            self._h, _ptr(free), _ptr(jac), int(bool(fresh))))
 
-    def shard_jac_to_host(self, d_jac_shard, host_jac, node_begin, node_end):
+    def shard_jac_to_host(self, d_jac_shard, host_jac, node_begin, node_end,
+                          fresh):
         """``opty_hip_shard_jac_to_host``: the blocks of a node shard from
         device memory into the dense page-locked host vector of the global
-        problem (only what changed after the first time)."""
+        problem (only what changed after the first time with this mapping of
+        the vector: ``fresh`` says when it is a new one)."""
         _check(self._lib.opty_hip_shard_jac_to_host(
-            self._h, _ptr(d_jac_shard), _ptr(host_jac), node_begin, node_end))
+            self._h, _ptr(d_jac_shard), _ptr(host_jac), node_begin, node_end,
+            int(bool(fresh))))
 
     def eval_con_jac(self, free, con, jac, mem):
         _check(self._lib.opty_hip_eval_con_jac(

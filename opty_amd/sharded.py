@@ -94,10 +94,17 @@ class SharedHostVector(object):
     current CUDA device).
     """
 
+    _mappings = 0
+
     def __init__(self, name, count, rank, group=None, owner=0, pin=True,
                  device=None):
         import torch.distributed as dist
         self.count = int(count)
+        # identity of THIS mapping: a later vector can be mapped at the same
+        # address, where a handle still believes its invariant entries to be
+        # (ShardedCollocator.to_host passes `fresh` by this token)
+        SharedHostVector._mappings += 1
+        self.token = SharedHostVector._mappings
         self._pinned = False
         self.array = None
         multi = dist.is_available() and dist.is_initialized()
@@ -592,8 +599,12 @@ class ShardedCollocator(object):
                 # on the device, scattered into the shared vector by this
                 # process's host threads); synchronous
                 self._use_stream()
+                token = getattr(jac_host, 'token', None)
+                fresh = token is None or \
+                    token != getattr(self, '_host_jac_token', None)
                 self.collocator.hip.shard_jac_to_host(
-                    jac, jac_host.array, self.a, self.b)
+                    jac, jac_host.array, self.a, self.b, fresh)
+                self._host_jac_token = token
             else:
                 jac_host.torch_view(self.a*self.P, self.b*self.P).copy_(
                     jac, non_blocking=True)

@@ -195,9 +195,9 @@ def test_round3_entry_points_reject_misuse():
     free = problems.make_free(col.num_free)
     jac = hb.pinned_empty(hip.nnz)
     with pytest.raises(hb.HipBackendError, match='parameter'):
-        hip.eval_jac_persistent(free, jac)          # not configured yet
+        hip.eval_jac_persistent(free, jac, True)    # not configured yet
     with pytest.raises(hb.HipBackendError, match='null'):
-        hip.eval_jac_persistent(None, jac)
+        hip.eval_jac_persistent(None, jac, True)
     dfree = torch.from_numpy(free).cuda()
     tail = torch.empty(4, dtype=torch.float64, device='cuda')
     with pytest.raises(hb.HipBackendError, match='parameter'):
@@ -207,9 +207,9 @@ def test_round3_entry_points_reject_misuse():
     djac = torch.empty(10*P, dtype=torch.float64, device='cuda')
     ncn = col.num_collocation_nodes - 1
     with pytest.raises(hb.HipBackendError, match='outside'):
-        hip.shard_jac_to_host(djac, jac, ncn - 5, ncn + 5)
+        hip.shard_jac_to_host(djac, jac, ncn - 5, ncn + 5, True)
     with pytest.raises(hb.HipBackendError, match='null'):
-        hip.shard_jac_to_host(djac, None, 0, 10)
+        hip.shard_jac_to_host(djac, None, 0, 10, True)
     hip.close()
     # problems without instance constraints: eval_instance is a no-op
     col2, hip2, _ = _fresh('config1_vyasarayani')

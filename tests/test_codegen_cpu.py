@@ -761,3 +761,63 @@ def test_hand_set_workgroup_width_is_narrowed_to_the_lds():
     for kern in meta['kernels'].values():
         assert kern['lds_bytes'] <= 160*1024
     assert meta['kernels']['jac']['waves_per_wg'] < 4
+
+
+@pytest.mark.parametrize('name,hot', [
+    ('config5_standin_24link_small', True), ('one_legged_small', True),
+    ('config3_10link_small', True),      # opty_con: 255 VGPRs, 2 SGPR spills
+    ('pend3_link_midpoint_small', False), ('msd_be_small', False)])
+def test_high_pressure_builds_are_marked_for_verification(name, hot):
+    """Kernels at the edge of the register file (>= 480 VGPRs or spilled
+    SGPRs: the 24-link stand-ins, the musculoskeletal model) are the ones
+    ``ConstraintCollocator._verify_build`` holds to an ``-O1`` twin before a
+    handle is handed out; ``prebuild`` leaves that twin in the cache."""
+    col = ConstraintCollocator(**problems.build(name))
+    hsaco, meta = col.prebuild()
+    marked = hb.high_pressure_kernels(hsaco)
+    assert bool(marked) == hot, marked
+    if hot:
+        # the twin: same source, -O1 -- a cache hit now
+        before = set(os.listdir(os.path.dirname(hsaco)))
+        twin = hb.compile_module(col._built_source, col.tmp_dir,
+                                 opt_level='-O1')
+        assert twin != hsaco and os.path.basename(twin) in before
+
+
+def test_kernel_metadata_guard_fails_closed(tmp_path):
+    """A code object whose metadata cannot be read, or that holds none of the
+    expected kernels, is an error -- not "no spills"."""
+    bogus = tmp_path/'x.hsaco'
+    bogus.write_bytes(b'not a code object')
+    with pytest.raises(hb.HipBackendError):
+        hb.vgpr_spills(str(bogus))
+    col = ConstraintCollocator(**problems.build('msd_be_small'))
+    hsaco, _ = col._build_code_object()
+    with pytest.raises(hb.HipBackendError, match='none of the kernels'):
+        hb.vgpr_spills(hsaco, kernels=('no_such_kernel',))
+    assert hb.vgpr_spills(hsaco) == {}
+    assert os.path.exists(hsaco + '.resources.json')
+
+
+def test_scatter_pool_honours_the_process_affinity_mask():
+    """The host threads that scatter the varying Jacobian entries stay inside
+    the affinity mask of the thread that created the pool and never outnumber
+    its CPUs (a ``taskset`` / cpuset of the host application);
+    ``OPTY_HIP_HOST_AFFINITY=wide`` lifts the cap."""
+    import subprocess
+    import sys
+    code = ('from opty_amd import hip_backend as hb; hb.set_host_threads(5); '
+            'print(hb.host_threads())')
+    cpu = sorted(os.sched_getaffinity(0))[0]
+
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        env.pop('OPTY_HIP_HOST_THREADS', None)
+        out = subprocess.run(['taskset', '-c', str(cpu), sys.executable, '-c',
+                              code], capture_output=True, text=True,
+                             cwd=REPO, env=env, check=True)
+        return int(out.stdout.strip().splitlines()[-1])
+    if shutil.which('taskset') is None:
+        pytest.skip('no taskset')
+    assert run({}) == 1
+    assert run({'OPTY_HIP_HOST_AFFINITY': 'wide'}) == 5

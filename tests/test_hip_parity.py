@@ -5,6 +5,8 @@ reference and (b) the CPU oracle on the same seeded inputs.
 Bar (BASELINE.json north_star): Jacobian sparsity indices bit-exact, float64
 constraint / Jacobian values within 1e-10 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -770,7 +772,7 @@ def test_persistent_jacobian_moves_only_what_changed(name, N):
     dense = hb.pinned_empty(hip.nnz)
     P, ncn = hip.desc['P'], N - 1
     unique, copies = varying_copies(col._build_program())
-    if 2*len(unique) > P:       # the runtime moves whole blocks then
+    if len(unique) > hb.pack_ratio()*P:   # the runtime moves whole blocks
         copies = []
     if name == 'config3_10link':
         assert len(copies) == 55
@@ -803,6 +805,80 @@ def test_persistent_jacobian_moves_only_what_changed(name, N):
     finally:
         hb.set_host_threads(0)
     assert hb.host_threads() >= 1
+
+
+def test_persistent_jacobian_does_not_trust_a_reused_address():
+    """A host vector at the address of an earlier one is NOT taken to hold
+    the invariant entries: the closure of ``generate_jacobian_function`` says
+    ``fresh`` on its first call, and ``fresh`` re-sends whole blocks
+    (``opty_hip_eval_jac_persistent``; an allocator hands freed page-locked
+    blocks out again at the same address)."""
+    from opty_amd import hip_backend as hb
+    col = _collocator('config3_10link', num_nodes=20001)
+    hip = col.hip
+    free1, free2 = (problems.make_free(col.num_free, seed=s) for s in (5, 6))
+    dense = hb.pinned_empty(hip.nnz)
+    vec = hb.pinned_empty(hip.nnz)
+    hip.eval_jac_persistent(free1, vec, True)
+    hip.eval_jac(free1, dense, hb.HOST)
+    np.testing.assert_allclose(vec, dense, rtol=1e-13, atol=0)
+    # the "reallocated" vector: same address, other contents
+    vec[:] = np.nan
+    hip.eval_jac_persistent(free2, vec, True)
+    hip.eval_jac(free2, dense, hb.HOST)
+    np.testing.assert_allclose(vec, dense, rtol=1e-13, atol=0)
+    # what the flag protects against: without it only the varying entries
+    # are written and the rest of the vector is whatever was there
+    vec[:] = np.nan
+    hip.eval_jac_persistent(free1, vec, False)
+    assert np.isnan(vec).any()
+    # every closure starts fresh, whatever address its buffer got
+    for _ in range(3):
+        jac = col.generate_jacobian_function()
+        out = jac(free2)
+        np.testing.assert_allclose(out, dense, rtol=1e-13, atol=0)
+        out[:] = np.nan
+        del jac, out
+
+
+def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
+    """``_verify_build``: a build at the register limit is compared with its
+    ``-O1`` twin before the handle exists.  The real pair agrees (verdict
+    remembered next to the code object); a twin that computes something else
+    -- here: the module of slightly different equations, standing in for a
+    miscompiled build -- makes the constructor path raise."""
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    kw = problems.build('one_legged_small')
+    col = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path), **kw)
+    hip = col.hip                      # builds, verifies, creates the handle
+    assert col._build_verdict['ok'] and col._build_verdict['worst'] < 1e-12
+    assert 'opty_conjac' in col._build_verdict['kernels']
+    hsaco = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
+    assert any(os.path.exists(os.path.join(tmp_path, f + '.crosscheck.json'))
+               for f in hsaco)
+    hip.close()
+    # same geometry, other values
+    eom = kw['equations_of_motion']
+    wrong = opty_amd.ConstraintCollocator(
+        tmp_dir=str(tmp_path),
+        **dict(kw, equations_of_motion=eom.applyfunc(
+            lambda e: e*(1 + 2.0**-20))))
+    bad, _ = wrong._build_code_object()
+    col2 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'second'),
+                                         **kw)
+    real = hb.compile_module
+
+    def twin_is_wrong(source, *args, **kwargs):
+        if kwargs.get('opt_level') == '-O1':
+            return bad
+        return real(source, *args, **kwargs)
+    monkeypatch.setattr(hb, 'compile_module', twin_is_wrong)
+    with pytest.raises(hb.HipBackendError, match='disagrees'):
+        col2.hip
+    monkeypatch.setattr(hb, 'compile_module', real)
+    monkeypatch.setenv('OPTY_CROSS_CHECK', 'off')
+    assert col2.hip is not None          # the documented opt-out
 
 
 @pytest.mark.gpu
