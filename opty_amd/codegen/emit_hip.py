@@ -63,6 +63,14 @@ RESIDENT_WAVES = 1024
 #: opty_jac for n-link pendulums: 8 links (P = 666) 8, 10 links (990) 10-12,
 #: 14 links (1830) 18, 24 links (5100) >= 32.
 STRIP_ENTRIES = 100
+#: work-aware strip cuts (EmitOptions.cut='work'): blocks of up to this many
+#: 16-entry units (the dynamic programme evaluates O(units^2) strip costs),
+#: no strip wider than this multiple of an even share, and what one stored
+#: entry weighs next to one weighted operation
+WORK_CUT_MAX_UNITS = 128
+WORK_CUT_MAX_SHARE = 3.0
+WORK_CUT_MAX_WEIGHT = 2.0
+STORE_WEIGHT = 6
 #: The fused kernel shares every block with the constraint waves and wants
 #: fewer, wider strips the larger the block: best counts 6-7 / 9 / 10-12 / 20
 #: for P = 666 / 990 / 1830 / 5100, i.e. about 0.286 sqrt(P) (an empirical fit
@@ -95,7 +103,18 @@ class EmitOptions(object):
                  flush_unroll=4, waves=None, store_aux=18, con_rows_per_wave=0,
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
-                 fold_instance=None, inline_uniform=None, dear_first=0):
+                 fold_instance=None, inline_uniform=None, dear_first=0,
+                 cut='even'):
+        # where the strips of a node-major block are cut: 'even' = equal
+        # entry counts; 'work' = at the line boundaries that make the strips'
+        # total evaluation work smallest (_ModuleWriter.group_ranges): a
+        # block whose expensive entries share most of their sub-expressions
+        # (the muscle-driven leg: 74 of 348 entries are not structural
+        # zeros, every strip that touches rows 4-5 costs ~3400 of the
+        # block's 4460 weighted operations) is evaluated once instead of
+        # once per strip that happens to cross it
+        assert cut in ('even', 'work')
+        self.cut = cut
         # 1: the waves of a block are dispatched longest first -- constraint
         # waves, then the Jacobian strips by descending evaluation work --
         # instead of in entry order (a launch of a few rounds ends when its
@@ -197,6 +216,7 @@ class EmitOptions(object):
                  if self.fused_groups is not None else '') +
                 ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
                 ('' if self.con_split == 'work' else ' con_split=count') +
+                ('' if self.cut == 'even' else ' cut=work') +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -433,6 +453,7 @@ class _ModuleWriter(object):
         self.inline_uni = bool(inline_uniform)
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
         self._auto = None           # (G_live, G) of group_ranges()
+        self._wcost = {}            # weighted work of entry ranges
         self._con_nt = False        # constraint stores of the kernel in print
 
     # -- leaves -------------------------------------------------------------
@@ -516,6 +537,83 @@ class _ModuleWriter(object):
         return sum(1 for i in d.reachable(roots)
                    if d.op[i] not in (ir.CONST, ir.INPUT) and not d.uni[i])
 
+    def _weighted_cost(self, e0, e1):
+        """Weighted per-node operations of the strip ``[e0, e1)`` (plus the
+        15 entries past its end that its wave evaluates as well)."""
+        key = (e0, e1)
+        hit = self._wcost.get(key)
+        if hit is None:
+            d, p = self.dag, self.p
+            roots = {p.jac_out[v % p.P]
+                     for v in range(e0, self._virtual_end(e1))}
+            hit = self._wcost[key] = sum(
+                _node_weight(d, i) for i in d.reachable(roots))
+        return hit
+
+    def _work_cut(self, S, unit, nunits):
+        """``S`` contiguous strips with boundaries on multiples of ``unit``
+        entries that minimise ``sum(cost) + WORK_CUT_MAX_WEIGHT*max(cost)``
+        over the strips, ``cost`` = weighted evaluation work + store work.
+
+        The sum is what a launch of many blocks pays (every SIMD is busy:
+        sub-expressions shared by neighbouring entries should be evaluated by
+        ONE wave, not by every wave whose strip crosses them); the largest
+        strip is the critical path of a block and what its wave needs in
+        registers.  Exact for a given bound on the largest strip (dynamic
+        programme over the unit boundaries); the bound is swept over the
+        quantiles of all strip costs."""
+        P = self.p.P
+        wmax = max(1, int(-(-WORK_CUT_MAX_SHARE*nunits//S)))
+        ends = [u*unit for u in range(nunits)] + [P]    # boundary k -> entry
+        costs = {}
+        for a in range(nunits):
+            for b in range(a + 1, min(nunits, a + wmax) + 1):
+                costs[a, b] = self._weighted_cost(ends[a], ends[b]) + \
+                    STORE_WEIGHT*(ends[b] - ends[a])
+
+        def solve(bound):
+            INF = float('inf')
+            best = [{0: 0.0}]
+            back = []
+            for s in range(1, S + 1):
+                cur, frm = {}, {}
+                for b in range(s, nunits - (S - s) + 1):
+                    for a in range(max(s - 1, b - wmax), b):
+                        prev = best[s - 1].get(a)
+                        c = costs[a, b]
+                        if prev is None or c > bound:
+                            continue
+                        if prev + c < cur.get(b, INF):
+                            cur[b], frm[b] = prev + c, a
+                best.append(cur)
+                back.append(frm)
+            if nunits not in best[S]:
+                return None
+            cuts, b = [nunits], nunits
+            for s in range(S, 0, -1):
+                b = back[s - 1][b]
+                cuts.append(b)
+            cuts.reverse()
+            return cuts
+
+        levels = sorted(set(costs.values()))
+        picks = sorted({levels[min(len(levels) - 1, (k*len(levels))//24)]
+                        for k in range(25)} | {levels[-1]})
+        best_cuts, best_obj = None, None
+        for bound in picks:
+            cuts = solve(bound)
+            if cuts is None:
+                continue
+            cs = [costs[cuts[g], cuts[g + 1]] for g in range(S)]
+            obj = sum(cs) + WORK_CUT_MAX_WEIGHT*max(cs)
+            if best_obj is None or obj < best_obj:
+                best_cuts, best_obj = cuts, obj
+        if best_cuts is None:
+            b = [((g*nunits)//S)*unit for g in range(S)] + [P]
+            return [(b[g], b[g + 1]) for g in range(S)]
+        return [(ends[best_cuts[g]], ends[best_cuts[g + 1]])
+                for g in range(S)]
+
     def group_ranges(self, count=None):
         """Assigns the P entries of the block to G waves (``count`` of them,
         or the printer option ``groups``, or the automatic choice).  The block is cut
@@ -547,6 +645,9 @@ class _ModuleWriter(object):
                     b.append(min(rest, key=lambda x: abs(x - g*P/S)))
                 b.append(P)
                 return [(b[g], b[g + 1]) for g in range(S)]
+            if self.o.cut == 'work' and self.line_mode() and \
+                    1 < S < nunits <= WORK_CUT_MAX_UNITS:
+                return self._work_cut(S, unit, nunits)
             b = [((g*nunits)//S)*unit for g in range(S)] + [P]
             return [(b[g], b[g + 1]) for g in range(S)]
 

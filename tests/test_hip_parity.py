@@ -819,14 +819,17 @@ def test_persistent_jacobian_does_not_trust_a_reused_address():
     free1, free2 = (problems.make_free(col.num_free, seed=s) for s in (5, 6))
     dense = hb.pinned_empty(hip.nnz)
     vec = hb.pinned_empty(hip.nnz)
+    # (entries that repeat another entry's expression hold its value: a
+    # rounding apart from the kernel's own evaluation of the copy)
+    close = dict(rtol=1e-10, atol=1e-11)
     hip.eval_jac_persistent(free1, vec, True)
     hip.eval_jac(free1, dense, hb.HOST)
-    np.testing.assert_allclose(vec, dense, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(vec, dense, **close)
     # the "reallocated" vector: same address, other contents
     vec[:] = np.nan
     hip.eval_jac_persistent(free2, vec, True)
     hip.eval_jac(free2, dense, hb.HOST)
-    np.testing.assert_allclose(vec, dense, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(vec, dense, **close)
     # what the flag protects against: without it only the varying entries
     # are written and the rest of the vector is whatever was there
     vec[:] = np.nan
@@ -836,7 +839,7 @@ def test_persistent_jacobian_does_not_trust_a_reused_address():
     for _ in range(3):
         jac = col.generate_jacobian_function()
         out = jac(free2)
-        np.testing.assert_allclose(out, dense, rtol=1e-13, atol=0)
+        np.testing.assert_allclose(out, dense, **close)
         out[:] = np.nan
         del jac, out
 

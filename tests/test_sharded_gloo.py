@@ -159,7 +159,11 @@ def _worker(rank, world, port, name, N, out, seed=7):
     ('chaplygin_be_small', 100, 2),                 # M > n, 8 instance cons
     # known trajectories given as functions of free
     ('implicit_traj_be_small', 40, 2),              # 39 nodes: 20 + 19
-    ('implicit_traj_mid_small', 33, 3)])            # 32 nodes: 11 + 11 + 10
+    ('implicit_traj_mid_small', 33, 3),             # 32 nodes: 11 + 11 + 10
+    # eight ranks, the node count of BASELINE config 4's launch (99 999 =
+    # 8*12 499 + 7: seven shards one node longer than the last)
+    ('pend3_link_midpoint_small', 44, 8),           # 43 nodes: 3 x 6 + 5 x 5
+    ('gaitlike_3link_be_small', 48, 8)])            # 47 nodes: 7 x 6 + 5
 def test_shards_reassemble_to_full(tmp_path, name, N, world):
     from oracle.collocation_oracle import OracleCollocator
     import golden_util as gu
@@ -255,7 +259,9 @@ def _callback_worker(rank, world, port, name, N, out):
 @pytest.mark.parametrize('name,N,world', [
     ('msd_be_small', 24, 2), ('pend2_link_vardur_unkmass_small', 26, 3),
     ('gaitlike_3link_be_small', 41, 3), ('implicit_traj_be_small', 40, 2),
-    ('config2_pendulum_small', 101, 3)])
+    ('config2_pendulum_small', 101, 3),
+    ('config2_pendulum_small', 101, 8),             # 100 nodes: 4 x 13 + 4 x 12
+    ('gaitlike_3link_be_small', 48, 8)])
 def test_callbacks_served_by_all_ranks(tmp_path, name, N, world):
     """``ShardedCallbacks``: the solver's rank (here rank 1) gets
     ``constraints(free)`` / ``jacobian(free)`` of the whole problem --

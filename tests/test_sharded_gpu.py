@@ -310,24 +310,29 @@ def test_two_ranks_shard_config3_and_gather_to_the_reference(tmp_path):
             zi['cols'].reshape(b - a, P)[sel - a], z['cols_nodes'][pick])
 
 
-def test_bench_strong_scaling_two_ranks():
-    """``bench.py --gpus 2`` as the driver launches it (torch.distributed.run,
-    oversubscribed here): strong scaling of ONE problem, all three variants
-    in the line."""
+@pytest.mark.parametrize('world', [2, 8])
+def test_bench_strong_scaling_oversubscribed(world):
+    """``bench.py --gpus 2`` / ``--gpus 8`` as the driver launches it
+    (torch.distributed.run, all ranks on the one GPU here): strong scaling of
+    ONE problem, all three re-assembly variants in the line.  Eight ranks is
+    the dress rehearsal of BASELINE config 4 -- 99 999 = 7*12 500 + 12 499
+    constraint nodes, eight processes registering one shared host vector,
+    ``ShardedCallbacks`` with seven serving ranks -- so that the first run on
+    eight devices cannot die of a rank-count bug."""
     env = dict(os.environ, OPTY_BENCH_OVERSUBSCRIBE='1',
                HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'),
-           '--gpus', '2', '--steps', '5', '--warmup', '2', '--prewarm-ms',
-           '20', '--no-cpu-baseline']
+           '--gpus', str(world), '--steps', '5', '--warmup', '2',
+           '--prewarm-ms', '20', '--no-cpu-baseline']
     proc = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO,
-                          env=env, timeout=900)
+                          env=env, timeout=1500)
     assert proc.returncode == 0, proc.stderr[-3000:]
     line = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1]
     res = json.loads(line)
-    assert res['scaling'] == 'strong' and res['n_gpus'] == 2
-    assert res['config']['nodes_per_launch'] == 50000
+    assert res['scaling'] == 'strong' and res['n_gpus'] == world
+    assert res['config']['nodes_per_launch'] == -(-99999//world)
     assert set(res['config']['variants']) == {'gather', 'to_host',
                                               'callbacks'}
     assert res['config']['variants']['callbacks']['evals_per_s'] > 0
@@ -335,7 +340,7 @@ def test_bench_strong_scaling_two_ranks():
     # the line certifies itself: the benched launches of both ranks and every
     # re-assembly variant were checked against the reference's golden record
     ver = res['config']['verify']
-    assert ver['ok'] is True and ver['ranks'] == 2, ver
+    assert ver['ok'] is True and ver['ranks'] == world, ver
     assert ver['worst_rel'] <= 1e-10
     labels = ' '.join(ver['checked'])
     for tag in ('benched launch', 'gather', 'to_host', 'callbacks'):

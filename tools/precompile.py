@@ -42,10 +42,17 @@ def main():
             source, meta = col.generate_source()
             jobs.append((spec, meta, pool.submit(hb.compile_module, source)))
         for spec, meta, job in jobs:
-            print(spec, job.result(), {k: (v['groups'], v['waves_per_wg'],
-                                           v['lds_bytes'])
-                                        for k, v in meta['kernels'].items()
-                                        if 'waves_per_wg' in v}, flush=True)
+            hsaco = job.result()
+            res = hb.cached_kernel_resources(hsaco)
+            print(spec, os.path.basename(hsaco),
+                  {k: (v['groups'], v['waves_per_wg'], v['lds_bytes'])
+                   for k, v in meta['kernels'].items()
+                   if 'waves_per_wg' in v},
+                  'vgpr/spill/sgpr-spill', {
+                      k: (r['.vgpr_count'], r['.vgpr_spill_count'],
+                          r['.sgpr_spill_count']) for k, r in res.items()
+                      if k in ('opty_con', 'opty_jac', 'opty_conjac')},
+                  flush=True)
 
 
 if __name__ == '__main__':

@@ -29,7 +29,7 @@ def parse(spec):
     for item in filter(None, spec.split(',')):
         k, v = item.split('=')
         kw[k] = None if v == 'None' else (
-            v if k in ('ablate', 'con_split', 'small_flush') else int(v))
+            v if k in ('ablate', 'con_split', 'small_flush', 'cut') else int(v))
     return EmitOptions(**kw)
 
 
