@@ -59,6 +59,7 @@ enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
 
 #define OPTY_HIP_LAYOUT_COO 0
 #define OPTY_HIP_LAYOUT_CSR 1
+#define OPTY_HIP_LAYOUT_SEGMENTED 2
 
 typedef struct opty_hip_desc {
     int64_t N;            /* collocation (time) nodes                        */
@@ -88,7 +89,10 @@ typedef struct opty_hip_desc {
     int32_t layout;       /* OPTY_HIP_LAYOUT_COO: the reference's node-major
                              order jac[i*P + e]; OPTY_HIP_LAYOUT_CSR: sorted by
                              row then column, jac[S_j*(N-1) + i*L_j + pos]
-                             (needs opty_hip_set_block_pattern)              */
+                             (needs opty_hip_set_block_pattern);
+                             OPTY_HIP_LAYOUT_SEGMENTED: the block's entries in
+                             three node-major segments, jac[S_g*(N-1) + i*L_g
+                             + pos] (needs opty_hip_set_segments)            */
     int32_t inst_folded;  /* 1: opty_con / opty_jac / opty_conjac evaluate the
                              instance tails themselves when launched with one
                              workgroup more than the node blocks need (small
@@ -194,6 +198,28 @@ int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
                               const int32_t *src, int32_t count);
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
                                  double *jac, int32_t fresh);
+/* ---- OPTY_HIP_LAYOUT_SEGMENTED: a host-visible Jacobian without a scatter ---
+ * IPOPT takes the (row, col, value) triplets in any order
+ * (opty/direct_collocation.py:527-562 hands it rows / cols once, :552-562 the
+ * values per call).  In this layout the dense block of the reference
+ * (:2589-2593) is stored as three node-major segments,
+ *
+ *   jac = [ seg 0 of node 0 .. N-2 | seg 1 of node 0 .. N-2 | seg 2 ... | tail ]
+ *
+ * order[0 .. P): the block entries (reference numbering e = j*C + k) in
+ * stored order -- seg_len[0] entries that can differ between two evaluations,
+ * then seg_len[1] entries that are the same expression as an entry of segment
+ * 0 (copy_source[k]: its position in segment 0), then seg_len[2] entries that
+ * depend on known parameters and the node time interval alone.  The kernels
+ * and opty_hip_jacobian_indices follow that order; HOST evaluations move
+ * segment 0 over PCIe straight into the head of the caller's vector, fill
+ * segment 1 on the host from it, and -- opty_hip_eval_jac_persistent -- leave
+ * segment 2 alone after the first call (re-sent after
+ * opty_hip_set_known_parameters / opty_hip_set_interval and when `fresh`).
+ * No read-for-ownership of the dense vector, no per-entry scatter.  Whole
+ * problems only (node shards use the node-major layout). */
+int opty_hip_set_segments(opty_hip_problem *p, const int32_t *order,
+                          const int32_t *seg_len, const int32_t *copy_source);
 /* Largest fraction of a block's stored entries for which only the varying
  * ones are moved (beyond it whole blocks are copied and no entry copies are
  * applied): 0.8, or OPTY_HIP_PACK_RATIO. */

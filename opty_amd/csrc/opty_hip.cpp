@@ -193,6 +193,13 @@ public:
         const int *copy_dst = nullptr, *copy_src = nullptr;
         int nruns = 0, V = 0, chunks = 0, ncopies = 0;
         long long P = 0, nodes = 0;
+        // segmented layout: seg_dst[i*L1 + k] = seg_src[i*L0 + seg_pos[k]]
+        // (the repeated entries, filled from the varying entries that have
+        // landed at the head of the same vector)
+        const double *seg_src = nullptr;
+        double *seg_dst = nullptr;
+        const int *seg_pos = nullptr;
+        int L0 = 0, L1 = 0;
     };
 
     static ScatterPool &instance() {
@@ -398,6 +405,15 @@ private:
                                 b = j.nodes*(c + 1)/j.chunks;
                 const long long i0 = a + (b - a)*t/T,
                                 i1 = a + (b - a)*(t + 1)/T;
+                if (j.seg_dst) {
+                    for (long long i = i0; i < i1; ++i) {
+                        const double *src = j.seg_src + i*j.L0;
+                        double *dst = j.seg_dst + i*j.L1;
+                        for (int k = 0; k < j.L1; ++k)
+                            dst[k] = src[j.seg_pos[k]];
+                    }
+                    continue;
+                }
                 for (long long i = i0; i < i1; ++i) {
                     const double *src = j.packed + i*j.V;
                     double *dst = j.dense + i*j.P;
@@ -469,6 +485,15 @@ struct opty_hip_problem {
     double *d_packed = nullptr, *h_packed = nullptr;
     // page-locked, device-mapped staging of the latency path (eval_mapped)
     double *h_free = nullptr, *h_con = nullptr, *h_jac = nullptr;
+    // OPTY_HIP_LAYOUT_SEGMENTED (opty_hip_set_segments): block entries in
+    // stored order, the lengths of the three segments, for every entry of
+    // segment 1 the position in segment 0 it repeats
+    std::vector<int> seg_order, seg_copy_src;
+    int seg_len[3] = {0, 0, 0};
+    bool have_segments = false;
+    int *d_seg_order = nullptr;
+    double *d_dense = nullptr;   // node-major blocks the kernels write
+    double *d_seg = nullptr;     // the same values in segmented order
     std::vector<hipEvent_t> chunk_events;
     size_t packed_cap = 0;                // doubles in d_packed / h_packed
     const double *static_host = nullptr;  // vector whose invariant entries
@@ -648,7 +673,7 @@ int check_shard(const opty_hip_problem *p, int what, const double *free_,
         what != OPTY_HIP_EVAL_PAIR && what != OPTY_HIP_EVAL_FUSED)
         return fail("bad evaluation selector %d", what);
     if (p->d.layout != OPTY_HIP_LAYOUT_COO)
-        return fail("the CSR layout is not node-sharded");
+        return fail("only the node-major layout is node-sharded");
     if (node_begin < 0 || node_end < node_begin ||
         node_end > p->ncon_nodes())
         return fail("shard [%lld, %lld) outside the %lld constraint nodes",
@@ -745,6 +770,9 @@ int eval_mapped(opty_hip_problem *p, int what, const double *free_,
     return 0;
 }
 
+int eval_segmented(opty_hip_problem *p, int what, const double *free_,
+                   double *con, double *jac, int mem, bool full);
+
 int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
              double *jac, int mem) {
     if (!p) return fail("null handle");
@@ -754,9 +782,12 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
     const bool want_jac = what != OPTY_HIP_EVAL_CON;
     if (!free_ || (want_con && !con) || (want_jac && !jac))
         return fail("null buffer");
+    if (mem != OPTY_HIP_HOST && mem != OPTY_HIP_DEVICE)
+        return fail("bad memory kind %d", mem);
+    if (p->d.layout == OPTY_HIP_LAYOUT_SEGMENTED && want_jac)
+        return eval_segmented(p, what, free_, con, jac, mem, true);
     if (mem == OPTY_HIP_DEVICE)
         return eval_device(p, what, free_, con, jac, whole(p), true);
-    if (mem != OPTY_HIP_HOST) return fail("bad memory kind %d", mem);
     // Small problems (BASELINE config 2: 240 KB in, 160 KB + 960 KB out) are
     // bound by the latency of the copies, not by their bytes: a pageable
     // hipMemcpyAsync costs 15-20 us whatever it moves.  Their kernels read
@@ -1152,8 +1183,13 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
         return fail("P = %d stored entries per block, block is %d x %d",
                     desc->P, desc->M, desc->C);
     if (desc->layout != OPTY_HIP_LAYOUT_COO &&
-        desc->layout != OPTY_HIP_LAYOUT_CSR)
+        desc->layout != OPTY_HIP_LAYOUT_CSR &&
+        desc->layout != OPTY_HIP_LAYOUT_SEGMENTED)
         return fail("bad layout %d", desc->layout);
+    if (desc->layout == OPTY_HIP_LAYOUT_SEGMENTED &&
+        desc->P != desc->M*desc->C)
+        return fail("the segmented layout stores the whole %d x %d block",
+                    desc->M, desc->C);
     if (desc->jac_wgs_per_block < 1 || desc->jac_waves_per_wg < 1 ||
         desc->jac_waves_per_wg > 16 || desc->fused_wgs_per_block < 1 ||
         desc->con_wgs_per_block < 1 || desc->fused_waves_per_wg < 1 ||
@@ -1226,7 +1262,8 @@ int opty_hip_destroy(opty_hip_problem *p) {
     void *bufs[] = {p->d_pattern, p->d_rowinfo, p->d_uni, p->d_params,
                     p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
-                    p->d_cols, p->d_var, p->d_packed};
+                    p->d_cols, p->d_var, p->d_packed, p->d_seg_order,
+                    p->d_dense, p->d_seg};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     void *pinned[] = {p->h_packed, p->h_free, p->h_con, p->h_jac};
@@ -1422,13 +1459,15 @@ static int indices_impl(opty_hip_problem *p, int64_t N_global,
     d.method = p->d.method;
     d.P = p->d.P;
     d.pattern = p->d_pattern;
-    d.rowinfo = p->d.layout == OPTY_HIP_LAYOUT_CSR ? p->d_rowinfo : nullptr;
+    d.rowinfo = p->d.layout != OPTY_HIP_LAYOUT_COO ? p->d_rowinfo : nullptr;
     if (p->d.layout == OPTY_HIP_LAYOUT_CSR && !p->d_rowinfo)
         return fail("the CSR block pattern was never set "
                     "(opty_hip_set_block_pattern)");
-    if (p->d.layout == OPTY_HIP_LAYOUT_CSR &&
+    if (p->d.layout == OPTY_HIP_LAYOUT_SEGMENTED && !p->have_segments)
+        return fail("the segments were never set (opty_hip_set_segments)");
+    if (p->d.layout != OPTY_HIP_LAYOUT_COO &&
         (node_offset != 0 || count != N_global - 1))
-        return fail("the CSR layout is not node-sharded");
+        return fail("only the node-major layout is node-sharded");
     if (p->d.P != p->d.M*p->d.C && !p->d_pattern)
         return fail("the block pattern was never set "
                     "(opty_hip_set_block_pattern)");
@@ -1488,8 +1527,8 @@ int opty_hip_jacobian_indices_shard(opty_hip_problem *p, int64_t N_global,
         return fail("a slab handle cannot carry instance constraints (their "
                     "free indices are global): use one global handle and "
                     "opty_hip_jacobian_indices_range");
-    if (p->d.layout == OPTY_HIP_LAYOUT_CSR)
-        return fail("the CSR layout is not node-sharded");
+    if (p->d.layout != OPTY_HIP_LAYOUT_COO)
+        return fail("only the node-major layout is node-sharded");
     return indices_impl(p, N_global, node_offset, p->ncon_nodes(), false,
                         rows, cols, mem);
 }
@@ -1798,6 +1837,18 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     if (!free_ || !jac) return fail("null buffer");
     if (int rc = use_device(p)) return rc;
     if (int rc = check_ready(p)) return rc;
+    if (p->d.layout == OPTY_HIP_LAYOUT_SEGMENTED) {
+        // the invariant segment stays in `jac` between calls
+        const bool all = fresh != 0 || !p->static_valid ||
+                         p->static_host != jac;
+        p->static_valid = false;
+        if (int rc = eval_segmented(p, OPTY_HIP_EVAL_JAC, free_, nullptr, jac,
+                                    OPTY_HIP_HOST, all))
+            return rc;
+        p->static_host = jac;
+        p->static_valid = true;
+        return 0;
+    }
     const long long P = p->P(), ncn = p->ncon_nodes();
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
     if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
@@ -1837,7 +1888,7 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
                     (long long)node_begin, (long long)node_end,
                     (long long)p->ncon_nodes());
     if (p->d.layout != OPTY_HIP_LAYOUT_COO)
-        return fail("the CSR layout is not node-sharded");
+        return fail("only the node-major layout is node-sharded");
     if (int rc = use_device(p)) return rc;
     if (int rc = order_streams(p)) return rc;
     const bool full = fresh != 0 || !p->shard_valid ||
@@ -1856,6 +1907,189 @@ int opty_hip_shard_jac_to_host(opty_hip_problem *p, const double *d_jac_shard,
     p->shard_valid = true;
     return 0;
 }
+
+int opty_hip_set_segments(opty_hip_problem *p, const int32_t *order,
+                          const int32_t *seg_len,
+                          const int32_t *copy_source) {
+    if (!p || !order || !seg_len) return fail("null argument");
+    if (p->d.layout != OPTY_HIP_LAYOUT_SEGMENTED)
+        return fail("segments apply to OPTY_HIP_LAYOUT_SEGMENTED only");
+    const int P = p->d.P;
+    const int L0 = seg_len[0], L1 = seg_len[1], L2 = seg_len[2];
+    if (L0 < 0 || L1 < 0 || L2 < 0 || L0 + L1 + L2 != P)
+        return fail("segment lengths %d + %d + %d do not add up to the %d "
+                    "entries of a block", L0, L1, L2, P);
+    if (L1 > 0 && !copy_source) return fail("null copy sources");
+    std::vector<char> seen((size_t)P, 0);
+    for (int e = 0; e < P; ++e) {
+        if (order[e] < 0 || order[e] >= P || seen[(size_t)order[e]])
+            return fail("the stored order is not a permutation of the "
+                        "block's %d entries", P);
+        seen[(size_t)order[e]] = 1;
+    }
+    for (int k = 0; k < L1; ++k)
+        if (copy_source[k] < 0 || copy_source[k] >= L0)
+            return fail("entry %d of segment 1 repeats position %d, outside "
+                        "segment 0 (%d entries)", k, copy_source[k], L0);
+    if (int rc = use_device(p)) return rc;
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    p->seg_order.assign(order, order + P);
+    p->seg_copy_src.assign(copy_source, copy_source + L1);
+    p->seg_len[0] = L0;
+    p->seg_len[1] = L1;
+    p->seg_len[2] = L2;
+    // (j, k) of every stored entry and the segment it lies in: what the
+    // index kernel needs (rows / cols in the order of the values)
+    std::vector<int32_t> jk(2*(size_t)P), info(2*(size_t)P);
+    const int start[4] = {0, L0, L0 + L1, P};
+    for (int sgm = 0; sgm < 3; ++sgm)
+        for (int e = start[sgm]; e < start[sgm + 1]; ++e) {
+            jk[2*(size_t)e] = order[e]/p->d.C;
+            jk[2*(size_t)e + 1] = order[e]%p->d.C;
+            info[2*(size_t)e] = start[sgm];
+            info[2*(size_t)e + 1] = start[sgm + 1] - start[sgm];
+        }
+    if (int rc = ensure(&p->d_pattern, jk.size())) return rc;
+    if (int rc = ensure(&p->d_rowinfo, info.size())) return rc;
+    if (int rc = ensure(&p->d_seg_order, (size_t)P)) return rc;
+    HIP_TRY(hipMemcpy(p->d_pattern, jk.data(), jk.size()*sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_rowinfo, info.data(), info.size()*sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->d_seg_order, order, (size_t)P*sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    p->have_segments = true;
+    p->static_valid = p->shard_valid = false;
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// gathers segment `sgm` of every node's block from the node-major vector
+int pack_segment(opty_hip_problem *p, const double *dense, double *out,
+                 int sgm, long long count) {
+    const int start[3] = {0, p->seg_len[0], p->seg_len[0] + p->seg_len[1]};
+    const int L = p->seg_len[sgm];
+    const long long total = count*L;
+    if (total <= 0) return 0;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255)/256,
+                                                        8192);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(opty_pack_kernel, dim3(grid), dim3(256), 0, p->stream,
+                       dense, out, p->d_seg_order + start[sgm], L, p->P(),
+                       total);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// OPTY_HIP_LAYOUT_SEGMENTED: the kernels write the node-major blocks into a
+// staging vector; the caller gets [segment 0 of all nodes | segment 1 of all
+// nodes | segment 2 of all nodes | instance tail].  HOST: segment 0 (the
+// entries that vary) crosses PCIe in chunks straight into the head of `jac`,
+// segment 1 (entries that repeat one of segment 0) is filled from that head
+// by the host threads while the next chunk is in flight, segment 2 (the
+// node-invariant entries) moves only when `full`.
+int eval_segmented(opty_hip_problem *p, int what, const double *free_,
+                   double *con, double *jac, int mem, bool full) {
+    if (!p->have_segments)
+        return fail("the segments were never set (opty_hip_set_segments)");
+    const bool want_con = what != OPTY_HIP_EVAL_JAC;
+    const long long P = p->P(), ncn = p->ncon_nodes();
+    const long long L0 = p->seg_len[0], L1 = p->seg_len[1];
+    const size_t tail = (size_t)p->d.nnz_inst;
+    if (int rc = ensure(&p->d_dense, (size_t)p->nnz())) return rc;
+    const double *dfree = free_;
+    double *dcon = con;
+    if (mem == OPTY_HIP_HOST) {
+        if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+        if (want_con)
+            if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
+        if (int rc = ensure(&p->d_seg, (size_t)p->nnz())) return rc;
+        if (int rc = order_streams(p)) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
+                               hipMemcpyHostToDevice, p->stream));
+        dfree = p->d_free;
+        dcon = want_con ? p->d_con : nullptr;
+    }
+    if (int rc = eval_device(p, what, dfree, dcon, p->d_dense, whole(p),
+                             true))
+        return rc;
+    if (mem == OPTY_HIP_DEVICE) {
+        for (int sgm = 0, at = 0; sgm < 3; at += p->seg_len[sgm], ++sgm)
+            if (int rc = pack_segment(p, p->d_dense, jac + (long long)at*ncn,
+                                      sgm, ncn))
+                return rc;
+        if (tail)
+            HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_dense + P*ncn,
+                                   tail*sizeof(double),
+                                   hipMemcpyDeviceToDevice, p->stream));
+        return 0;
+    }
+    if (want_con)
+        HIP_TRY(hipMemcpyAsync(con, p->d_con, p->num_con()*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    if (tail)
+        HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_dense + P*ncn,
+                               tail*sizeof(double), hipMemcpyDeviceToHost,
+                               p->stream));
+    if (full && p->seg_len[2] > 0) {
+        double *d2 = p->d_seg + (L0 + L1)*ncn;
+        if (int rc = pack_segment(p, p->d_dense, d2, 2, ncn)) return rc;
+        HIP_TRY(hipMemcpyAsync(jac + (L0 + L1)*ncn, d2,
+                               (size_t)p->seg_len[2]*ncn*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    }
+    int chunks = 0;
+    if (L0 > 0) {
+        if (int rc = pack_segment(p, p->d_dense, p->d_seg, 0, ncn)) return rc;
+        const size_t bytes = (size_t)L0*ncn*sizeof(double);
+        chunks = (int)std::max<size_t>(1, std::min<size_t>(
+            32, bytes/(16u << 20)));
+        chunks = (int)std::min<long long>(chunks, ncn);
+        while ((int)p->chunk_events.size() < chunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            p->chunk_events.push_back(e);
+        }
+        for (int c = 0; c < chunks; ++c) {
+            const long long a = ncn*c/chunks, b = ncn*(c + 1)/chunks;
+            HIP_TRY(hipMemcpyAsync(jac + a*L0, p->d_seg + a*L0,
+                                   (size_t)(b - a)*L0*sizeof(double),
+                                   hipMemcpyDeviceToHost, p->stream));
+            HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
+        }
+    }
+    int rc = 0;
+    if (L1 > 0 && chunks > 0) {
+        ScatterPool &pool = ScatterPool::instance();
+        pool.set_numa_node(host_numa_node(jac));
+        ScatterPool::Job job;
+        job.seg_src = jac;
+        job.seg_dst = jac + L0*ncn;
+        job.seg_pos = p->seg_copy_src.data();
+        job.L0 = (int)L0;
+        job.L1 = (int)L1;
+        job.chunks = chunks;
+        job.nodes = ncn;
+        pool.start(job);
+        for (int c = 0; c < chunks; ++c) {
+            const hipError_t e = hipEventSynchronize(p->chunk_events[c]);
+            if (e != hipSuccess && rc == 0)
+                rc = fail("hipEventSynchronize: %s", hipGetErrorString(e));
+            pool.ready(c + 1);     // (also after an error: frees the workers)
+        }
+        pool.wait();
+    }
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
 
 int opty_hip_host_numa_node(const void *ptr) {
     if (!ptr) return -1;

@@ -51,6 +51,13 @@ class ConstraintCollocator(object):
       node shards, :mod:`opty_amd.sharded`) and
       ``jacobian_layout='csr'``: opt-in, stores the Jacobian values sorted by
       row then column (see ``jacobian_csr_structure``);
+      ``jacobian_layout='varying_first'``: opt-in, for solvers on the host:
+      the same triplets as the reference's, ordered ``[entries that can
+      change, all nodes | entries that repeat one of those | node-invariant
+      entries | instance partials]`` (IPOPT takes triplets in any order,
+      ``opty/direct_collocation.py:527-562``), so that ``jacobian(free)``
+      is one PCIe stream into the head of the persistent array -- no host
+      scatter (see ``jacobian_segments``);
       ``prune_zeros``: opt-in, drops the structurally zero entries of the
       per-node block from ``jacobian(free)`` / ``jacobian_indices()`` (the
       reference keeps them, ``opty/direct_collocation.py:2589-2593``; 61 % of
@@ -73,8 +80,12 @@ class ConstraintCollocator(object):
         # constraint nodes one launch covers (a node shard evaluates fewer
         # than N - 1): picks the kernels' strip count for small launches
         self._launch_nodes = launch_nodes
-        if jacobian_layout not in ('coo', 'csr'):
-            raise ValueError('jacobian_layout must be "coo" or "csr".')
+        if jacobian_layout not in ('coo', 'csr', 'varying_first'):
+            raise ValueError('jacobian_layout must be "coo", "csr" or '
+                             '"varying_first".')
+        if jacobian_layout == 'varying_first' and prune_zeros:
+            raise ValueError("jacobian_layout='varying_first' keeps the "
+                             "reference's dense block: not with prune_zeros.")
         self._jacobian_layout = jacobian_layout
         self._eom = sm.ImmutableDenseMatrix(equations_of_motion)
         if self._eom.shape[1] != 1:
@@ -521,7 +532,7 @@ class ConstraintCollocator(object):
             self.time_interval_symbol, self._variable_duration,
             self._wrt(), self.integration_method, instance,
             implicit=self._implicit_chain(), prune_zeros=self._prune_zeros,
-            layout=self._jacobian_layout)
+            layout='csr' if self._jacobian_layout == 'csr' else 'coo')
         return self._program
 
     def generate_source(self):
@@ -721,6 +732,8 @@ class ConstraintCollocator(object):
             free[-1] = 0.01
         desc = dict(self._descriptor(meta), N=N, num_inst=0, nnz_inst=0,
                     num_inst_atoms=0, inst_folded=0)
+        if self._jacobian_layout == 'varying_first':
+            desc['layout'] = 0          # the kernels write node-major blocks
         known = None
         if self.num_known_input_trajectories:
             known = np.ascontiguousarray(self._known_trajectory_array(
@@ -869,7 +882,8 @@ class ConstraintCollocator(object):
             num_uniform=meta['num_uniform'],
             uniform_dynamic=int(meta['uniform_dynamic']),
             device=self._device,
-            layout=1 if self._jacobian_layout == 'csr' else 0,
+            layout={'coo': 0, 'csr': 1,
+                    'varying_first': 2}[self._jacobian_layout],
             inst_folded=int(meta.get('inst_folded', False)))
 
     def _known_trajectory_array(self, free):
@@ -908,6 +922,9 @@ class ConstraintCollocator(object):
             self._uploaded_trajectories = None
         if self._program.pruned or self._jacobian_layout == 'csr':
             hip.set_block_pattern(self._program.pattern)
+        if self._jacobian_layout == 'varying_first':
+            order, seg_len, source = self.jacobian_segments()
+            hip.set_segments(order, seg_len, source)
         if self._jacobian_layout == 'coo':
             # entries that repeat another varying entry's expression are
             # filled on the host (OPTY_HOST_NO_COPIES=1: moved like the rest)
@@ -1138,7 +1155,8 @@ class ConstraintCollocator(object):
         # read-only -- cyipopt copies it).  OPTY_HOST_DENSE=1 moves the whole
         # vector every call.
         import os
-        persistent = (self._jacobian_layout == 'coo' and
+        persistent = (self._jacobian_layout == 'varying_first' or
+                      self._jacobian_layout == 'coo' and
                       hip.nnz >= self._PERSISTENT_MIN_NNZ and
                       os.environ.get('OPTY_HOST_DENSE') != '1')
 
@@ -1170,6 +1188,28 @@ class ConstraintCollocator(object):
         cols = np.empty(hip.nnz, dtype=np.int64)
         hip.jacobian_indices(rows, cols, hb.HOST)
         return rows, cols
+
+    def jacobian_segments(self):
+        """``(order, seg_len, copy_source)`` of ``jacobian_layout=
+        'varying_first'``: ``order[pos]`` = the reference's block entry
+        ``e = j*C + k`` stored at position ``pos`` of a node's block,
+        ``seg_len`` = lengths of the three segments -- entries that can
+        differ between two evaluations / entries that are the same
+        expression as one of those (``copy_source[k]``: the position of the
+        source in segment 0) / entries that depend on known parameters and
+        the node time interval alone.  ``jacobian(free)`` is
+        ``[seg 0 of all nodes | seg 1 of all nodes | seg 2 of all nodes |
+        instance partials]``, each segment node-major."""
+        prog = self._build_program()
+        unique, copies = varying_copies(prog)
+        taken = set(unique) | {d for d, _ in copies}
+        invariant = [e for e in range(prog.P) if e not in taken]
+        place = {e: k for k, e in enumerate(unique)}
+        order = list(unique) + [d for d, _ in copies] + invariant
+        return (np.array(order, dtype=np.int32),
+                np.array([len(unique), len(copies), len(invariant)],
+                         dtype=np.int32),
+                np.array([place[src] for _, src in copies], dtype=np.int32))
 
     def jacobian_csr_structure(self):
         """``(row_ptr, col_idx)`` (int64) of the constraint Jacobian in

@@ -291,6 +291,7 @@ _SIGNATURES = {
                                         [_P, _P, ctypes.c_int32]),
     'opty_hip_set_instance_indices': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_set_block_pattern': (ctypes.c_int, [_P, _P]),
+    'opty_hip_set_segments': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_num_free': (ctypes.c_int64, [_P]),
     'opty_hip_num_constraints': (ctypes.c_int64, [_P]),
     'opty_hip_nnz': (ctypes.c_int64, [_P]),
@@ -517,6 +518,18 @@ class HipProblem(object):
         jk = np.ascontiguousarray(pattern, dtype=np.int32).reshape(-1, 2)
         assert len(jk) == self.desc['P']
         _check(self._lib.opty_hip_set_block_pattern(self._h, _ptr(jk)))
+
+    def set_segments(self, order, seg_len, copy_source):
+        """``opty_hip_set_segments`` (``OPTY_HIP_LAYOUT_SEGMENTED``):
+        ``order``: the block entries in stored order, ``seg_len``: lengths of
+        the varying / repeated / invariant segments, ``copy_source``: for
+        every entry of segment 1 its source's position in segment 0."""
+        o = np.ascontiguousarray(order, dtype=np.int32)
+        n = np.ascontiguousarray(seg_len, dtype=np.int32)
+        c = np.ascontiguousarray(copy_source, dtype=np.int32)
+        assert len(o) == self.desc['P'] and len(n) == 3
+        _check(self._lib.opty_hip_set_segments(self._h, _ptr(o), _ptr(n),
+                                               _ptr(c)))
 
     def set_instance_indices(self, atom_index, rows, cols):
         a = np.ascontiguousarray(atom_index, dtype=np.int64)

@@ -237,8 +237,9 @@ class ShardedCollocator(object):
         import torch
         if kwargs.get('jacobian_layout', 'coo') != 'coo':
             raise NotImplementedError(
-                'the row-sorted (csr) layout is not node-sharded: a shard of '
-                'it is not a contiguous slice of the global value vector')
+                'only the node-major layout is node-sharded: a shard of the '
+                'row-sorted (csr) or varying-first layout is not a '
+                'contiguous slice of the global value vector')
         if rank is None or world_size is None:
             import torch.distributed as dist
             rank = dist.get_rank(group)
