@@ -465,6 +465,7 @@ struct opty_hip_problem {
     hipFunction_t k_con = nullptr, k_jac = nullptr, k_conjac = nullptr,
                   k_inst = nullptr, k_uni = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // device-to-host side of a pipeline
     double *d_params = nullptr, *d_known = nullptr, *d_uni = nullptr;
     bool uni_dirty = true;   // node-invariant table needs (re)computing
     long long *d_inst_idx = nullptr, *d_inst_rows = nullptr,
@@ -1273,6 +1274,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
     return 0;
@@ -1996,27 +1998,14 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
     if (!p->have_segments)
         return fail("the segments were never set (opty_hip_set_segments)");
     const bool want_con = what != OPTY_HIP_EVAL_JAC;
-    const long long P = p->P(), ncn = p->ncon_nodes();
+    const long long P = p->P(), ncn = p->ncon_nodes(), N = p->d.N;
     const long long L0 = p->seg_len[0], L1 = p->seg_len[1];
     const size_t tail = (size_t)p->d.nnz_inst;
     if (int rc = ensure(&p->d_dense, (size_t)p->nnz())) return rc;
-    const double *dfree = free_;
-    double *dcon = con;
-    if (mem == OPTY_HIP_HOST) {
-        if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
-        if (want_con)
-            if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
-        if (int rc = ensure(&p->d_seg, (size_t)p->nnz())) return rc;
-        if (int rc = order_streams(p)) return rc;
-        HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
-                               hipMemcpyHostToDevice, p->stream));
-        dfree = p->d_free;
-        dcon = want_con ? p->d_con : nullptr;
-    }
-    if (int rc = eval_device(p, what, dfree, dcon, p->d_dense, whole(p),
-                             true))
-        return rc;
     if (mem == OPTY_HIP_DEVICE) {
+        if (int rc = eval_device(p, what, free_, con, p->d_dense, whole(p),
+                                 true))
+            return rc;
         for (int sgm = 0, at = 0; sgm < 3; at += p->seg_len[sgm], ++sgm)
             if (int rc = pack_segment(p, p->d_dense, jac + (long long)at*ncn,
                                       sgm, ncn))
@@ -2027,6 +2016,106 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                                    hipMemcpyDeviceToDevice, p->stream));
         return 0;
     }
+    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+    if (want_con)
+        if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
+    if (int rc = ensure(&p->d_seg, (size_t)p->nnz())) return rc;
+    if (int rc = order_streams(p)) return rc;
+    double *dcon = want_con ? p->d_con : nullptr;
+    // Windows of nodes: the upload of `free`, the evaluation and the packing
+    // of window w + 1 run while window w crosses PCIe the other way (its own
+    // stream).  What is serial is one window's upload + evaluation, not the
+    // whole problem's (0.5 of 4.8 ms for the 10-link pendulum at N = 10^5).
+    // (An event recorded on hipStreamLegacy and waited for on another stream
+    // crashed inside the runtime, ROCm 7.0.2: one window there.)
+    const char *env_w = getenv("OPTY_HIP_HOST_WINDOWS");
+    const int want_windows = env_w ? std::max(1, std::min(64, atoi(env_w)))
+                                   : 0;
+    const size_t head_bytes = (size_t)L0*ncn*sizeof(double);
+    int W = want_windows ? want_windows
+                         : (head_bytes >= (32u << 20) ? 6 : 1);
+    if (p->stream == (hipStream_t)OPTY_HIP_STREAM_LEGACY) W = 1;
+    W = (int)std::min<long long>(W, std::max<long long>(1, ncn/64));
+    if (W > 1 && !p->copy_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
+                                         hipStreamNonBlocking));
+    hipStream_t out = W > 1 ? p->copy_stream : p->stream;
+    const long long rows = (long long)p->d.n + p->d.q;
+    const long long rest = p->num_free() - rows*N;      // parameters, h
+    // DMA chunks of about 16 MB: long enough for the engine's full rate,
+    // short enough that the host threads start early and finish soon after
+    // the last byte has landed
+    int chunks = 0;
+    if (L0 > 0) {
+        chunks = (int)std::max<size_t>(1, std::min<size_t>(
+            32, head_bytes/(16u << 20)));
+        chunks = (int)std::min<long long>(chunks, ncn);
+        chunks = std::max(chunks, W);
+    }
+    while ((int)p->chunk_events.size() < std::max(chunks, 1) + W) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->chunk_events.push_back(e);
+    }
+    if (rest > 0)
+        HIP_TRY(hipMemcpyAsync(p->d_free + rows*N, free_ + rows*N,
+                               (size_t)rest*sizeof(double),
+                               hipMemcpyHostToDevice, p->stream));
+    int next_chunk = 0;
+    for (int w = 0; w < W; ++w) {
+        const long long a = ncn*w/W, b = ncn*(w + 1)/W;
+        // time nodes [a, b] of every trajectory row (one-node halo; the
+        // first column of a later window is there already)
+        const long long c0 = w == 0 ? a : a + 1;
+        if (W == 1)
+            HIP_TRY(hipMemcpyAsync(p->d_free, free_,
+                                   (size_t)rows*N*sizeof(double),
+                                   hipMemcpyHostToDevice, p->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(p->d_free + c0, (size_t)N*sizeof(double),
+                                     free_ + c0, (size_t)N*sizeof(double),
+                                     (size_t)(b + 1 - c0)*sizeof(double),
+                                     (size_t)rows, hipMemcpyHostToDevice,
+                                     p->stream));
+        const NodeRange rg{a, b, ncn};
+        if (int rc = eval_device(p, what, p->d_free, dcon ? dcon + a : nullptr,
+                                 p->d_dense + a*P, rg, false))
+            return rc;
+        if (full && p->seg_len[2] > 0)
+            if (int rc = pack_segment(p, p->d_dense + a*P,
+                                      p->d_seg + (L0 + L1)*ncn +
+                                          a*p->seg_len[2], 2, b - a))
+                return rc;
+        if (L0 > 0)
+            if (int rc = pack_segment(p, p->d_dense + a*P, p->d_seg + a*L0, 0,
+                                      b - a))
+                return rc;
+        if (W > 1) {
+            hipEvent_t ready = p->chunk_events[(size_t)std::max(chunks, 1) +
+                                               (size_t)w];
+            HIP_TRY(hipEventRecord(ready, p->stream));
+            HIP_TRY(hipStreamWaitEvent(out, ready, 0));
+        }
+        // the chunks that end inside this window
+        while (next_chunk < chunks &&
+               ncn*(next_chunk + 1)/chunks <= b) {
+            const long long ca = ncn*next_chunk/chunks,
+                            cb = ncn*(next_chunk + 1)/chunks;
+            HIP_TRY(hipMemcpyAsync(jac + ca*L0, p->d_seg + ca*L0,
+                                   (size_t)(cb - ca)*L0*sizeof(double),
+                                   hipMemcpyDeviceToHost, out));
+            HIP_TRY(hipEventRecord(p->chunk_events[(size_t)next_chunk], out));
+            ++next_chunk;
+        }
+    }
+    // instance tails (they read the whole free vector), constraints, and --
+    // `full` -- the node-invariant segment, behind the entries that vary
+    if (p->d.num_inst > 0)
+        if (int rc = launch_instance(
+                p, p->d_free, want_con ? dcon + (long long)p->d.M*ncn
+                                       : nullptr,
+                p->d_dense + P*ncn))
+            return rc;
     if (want_con)
         HIP_TRY(hipMemcpyAsync(con, p->d_con, p->num_con()*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
@@ -2034,37 +2123,23 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
         HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_dense + P*ncn,
                                tail*sizeof(double), hipMemcpyDeviceToHost,
                                p->stream));
-    if (full && p->seg_len[2] > 0) {
-        double *d2 = p->d_seg + (L0 + L1)*ncn;
-        if (int rc = pack_segment(p, p->d_dense, d2, 2, ncn)) return rc;
-        HIP_TRY(hipMemcpyAsync(jac + (L0 + L1)*ncn, d2,
+    if (full && p->seg_len[2] > 0)
+        HIP_TRY(hipMemcpyAsync(jac + (L0 + L1)*ncn,
+                               p->d_seg + (L0 + L1)*ncn,
                                (size_t)p->seg_len[2]*ncn*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
-    }
-    int chunks = 0;
-    if (L0 > 0) {
-        if (int rc = pack_segment(p, p->d_dense, p->d_seg, 0, ncn)) return rc;
-        const size_t bytes = (size_t)L0*ncn*sizeof(double);
-        chunks = (int)std::max<size_t>(1, std::min<size_t>(
-            32, bytes/(16u << 20)));
-        chunks = (int)std::min<long long>(chunks, ncn);
-        while ((int)p->chunk_events.size() < chunks) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            p->chunk_events.push_back(e);
-        }
-        for (int c = 0; c < chunks; ++c) {
-            const long long a = ncn*c/chunks, b = ncn*(c + 1)/chunks;
-            HIP_TRY(hipMemcpyAsync(jac + a*L0, p->d_seg + a*L0,
-                                   (size_t)(b - a)*L0*sizeof(double),
-                                   hipMemcpyDeviceToHost, p->stream));
-            HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
-        }
-    }
+    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t0 = trace ? now() : 0.0;
+    double t_first = 0.0, t_last = 0.0;
     int rc = 0;
+    ScatterPool *pool = nullptr;
     if (L1 > 0 && chunks > 0) {
-        ScatterPool &pool = ScatterPool::instance();
-        pool.set_numa_node(host_numa_node(jac));
+        pool = &ScatterPool::instance();
+        pool->set_numa_node(host_numa_node(jac));
         ScatterPool::Job job;
         job.seg_src = jac;
         job.seg_dst = jac + L0*ncn;
@@ -2073,17 +2148,26 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
         job.L1 = (int)L1;
         job.chunks = chunks;
         job.nodes = ncn;
-        pool.start(job);
-        for (int c = 0; c < chunks; ++c) {
-            const hipError_t e = hipEventSynchronize(p->chunk_events[c]);
-            if (e != hipSuccess && rc == 0)
-                rc = fail("hipEventSynchronize: %s", hipGetErrorString(e));
-            pool.ready(c + 1);     // (also after an error: frees the workers)
-        }
-        pool.wait();
+        pool->start(job);
     }
+    for (int c = 0; c < chunks; ++c) {
+        const hipError_t e = hipEventSynchronize(p->chunk_events[(size_t)c]);
+        if (e != hipSuccess && rc == 0)
+            rc = fail("hipEventSynchronize: %s", hipGetErrorString(e));
+        if (trace && c == 0) t_first = now();
+        if (pool) pool->ready(c + 1);   // (also after an error: frees them)
+    }
+    if (trace) t_last = now();
+    if (pool) pool->wait();
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    if (W > 1) HIP_TRY(hipStreamSynchronize(out));
+    if (trace)
+        fprintf(stderr, "opty_hip: segmented, %lld nodes x %lld entries, %d "
+                "windows, %d chunks%s: first chunk landed +%.2f ms after "
+                "enqueue, last +%.2f, all done +%.2f\n", ncn, L0, W, chunks,
+                full ? " (+ invariant segment)" : "", t_first - t0,
+                t_last - t0, now() - t0);
     return 0;
 }
 

@@ -62,8 +62,15 @@ def _sorted_triplets(rows, cols, vals):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('windows', [None, '1', '3'])
 @pytest.mark.parametrize('name', CASES + GALLERY)
-def test_triplet_set_equals_the_reference(name):
+def test_triplet_set_equals_the_reference(name, windows, monkeypatch):
+    """``windows``: node windows of the host pipeline (upload / evaluate /
+    pack of one window while the previous one crosses PCIe; default: by
+    size), forced here so that small problems exercise ragged windows,
+    instance tails and a free ``h`` behind them."""
+    if windows:
+        monkeypatch.setenv('OPTY_HIP_HOST_WINDOWS', windows)
     import opty_amd
     from opty_amd import hip_backend as hb
     meta, z, kw = _load(name)
@@ -98,10 +105,13 @@ def test_triplet_set_equals_the_reference(name):
     seg0 = vals[:L0*N1].reshape(N1, L0)
     seg1 = vals[L0*N1:(L0 + L1)*N1].reshape(N1, L1)
     seg2 = vals[(L0 + L1)*N1:P*N1].reshape(N1, L2)
-    np.testing.assert_array_equal(seg0, blk[:, order[:L0]])
+    # (to rounding: which wave evaluates the entries next to a strip boundary
+    # depends on the alignment of the destination)
+    close = dict(rtol=1e-12, atol=1e-13*max(1.0, np.abs(blk).max()))
+    np.testing.assert_allclose(seg0, blk[:, order[:L0]], **close)
     np.testing.assert_array_equal(seg1, seg0[:, source])   # bit-equal copies
-    np.testing.assert_array_equal(seg2, blk[:, order[L0 + L1:]])
-    np.testing.assert_array_equal(vals[P*N1:], ref_vals[P*N1:])
+    np.testing.assert_allclose(seg2, blk[:, order[L0 + L1:]], **close)
+    np.testing.assert_allclose(vals[P*N1:], ref_vals[P*N1:], **close)
     # device-pointer evaluation returns the same layout
     import torch
     dfree = torch.from_numpy(z['free']).cuda()
@@ -111,12 +121,12 @@ def test_triplet_set_equals_the_reference(name):
     col.hip.eval_con_jac(dfree, dcon, djac, hb.DEVICE)
     col.hip.synchronize()
     dv = djac.cpu().numpy()
-    np.testing.assert_array_equal(dv[:L0*N1], vals[:L0*N1])
+    np.testing.assert_allclose(dv[:L0*N1], vals[:L0*N1], **close)
     np.testing.assert_allclose(dv, vals, rtol=1e-9, atol=1e-11*max(
         1.0, np.abs(vals).max()))
     np.testing.assert_allclose(
         dcon.cpu().numpy(), ref.generate_constraint_function()(z['free']),
-        rtol=0, atol=0)
+        rtol=1e-12, atol=1e-12)
 
 
 @pytest.mark.gpu
@@ -148,7 +158,7 @@ def test_large_problem_streams_into_the_head_of_the_vector():
             seg = v[at*N1:(at + L)*N1].reshape(N1, L)
             got[:, order[at:at + L]] = seg
             at += L
-        np.testing.assert_array_equal(got, blk)
+        np.testing.assert_allclose(got, blk, rtol=1e-12, atol=1e-10)
     # indices: the same permutation
     at = 0
     for L in (int(x) for x in seg_len):
