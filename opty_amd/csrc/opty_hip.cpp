@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1699,8 +1700,17 @@ static int host_numa_node(const void *addr) {
 // threads while the next chunk is in flight.  Synchronous.
 static bool packing_pays(const opty_hip_problem *p);
 
+//
+// `produce(a, b)`, when given with !full, enqueues the evaluation of the nodes
+// [a, b) of d_blocks on the handle's stream: the nodes are then evaluated and
+// packed in windows while the previous window crosses PCIe on a stream of its
+// own (the evaluation + packing of the whole problem, 0.2 of 5 ms for the
+// 10-link pendulum at N = 10^5, is no longer serial).
+typedef std::function<int(long long, long long)> Producer;
+
 static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
-                               double *h_blocks, long long count, bool full) {
+                               double *h_blocks, long long count, bool full,
+                               const Producer &produce = Producer()) {
     const int V = (int)p->var_entries.size();
     const long long P = p->P();
     if (count <= 0) return 0;
@@ -1729,7 +1739,8 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         }
         return 0;
     }
-    if (V == 0) return 0;       // a block of constants: nothing moves
+    if (V == 0)                 // a block of constants: nothing moves
+        return produce ? produce(0, count) : 0;
     const size_t packed = (size_t)count*V;
     if (packed > p->packed_cap) {
         HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
@@ -1748,24 +1759,54 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     int chunks = (int)std::max<size_t>(1, std::min<size_t>(
         32, packed*sizeof(double)/(16u << 20)));
     chunks = (int)std::min<long long>(chunks, count);
-    while ((int)p->chunk_events.size() < chunks) {
+    // windows (see `produce`); never on the legacy stream: an event
+    // recorded there and waited for on another stream crashed inside the
+    // runtime (ROCm 7.0.2)
+    int W = 1;
+    if (produce && p->stream != (hipStream_t)OPTY_HIP_STREAM_LEGACY &&
+        packed*sizeof(double) >= (32u << 20)) {
+        const char *env_w = getenv("OPTY_HIP_HOST_WINDOWS");
+        W = env_w ? std::max(1, std::min(64, atoi(env_w))) : 8;
+        W = (int)std::min<long long>(W, std::max<long long>(1, count/64));
+        chunks = std::max(chunks, W);
+    }
+    while ((int)p->chunk_events.size() < chunks + W) {
         hipEvent_t e;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         p->chunk_events.push_back(e);
     }
-    const unsigned grid = (unsigned)std::min<long long>(
-        ((long long)packed + 255)/256, 8192);
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(opty_pack_kernel, dim3(grid), dim3(256), 0, p->stream,
-                       d_blocks, p->d_packed, p->d_var, V, P,
-                       (long long)packed);
-    HIP_TRY(hipGetLastError());
-    for (int c = 0; c < chunks; ++c) {
-        const long long a = count*c/chunks, b = count*(c + 1)/chunks;
-        HIP_TRY(hipMemcpyAsync(p->h_packed + a*V, p->d_packed + a*V,
-                               (size_t)(b - a)*V*sizeof(double),
-                               hipMemcpyDeviceToHost, p->stream));
-        HIP_TRY(hipEventRecord(p->chunk_events[c], p->stream));
+    if (W > 1 && !p->copy_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
+                                         hipStreamNonBlocking));
+    hipStream_t out = W > 1 ? p->copy_stream : p->stream;
+    int next_chunk = 0;
+    for (int w = 0; w < W; ++w) {
+        const long long wa = count*w/W, wb = count*(w + 1)/W;
+        if (produce)
+            if (int rc = produce(wa, wb)) return rc;
+        const long long part = (wb - wa)*V;
+        const unsigned grid = (unsigned)std::min<long long>(
+            (part + 255)/256, 8192);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(opty_pack_kernel, dim3(grid), dim3(256), 0,
+                           p->stream, d_blocks + wa*P, p->d_packed + wa*V,
+                           p->d_var, V, P, part);
+        HIP_TRY(hipGetLastError());
+        if (W > 1) {
+            hipEvent_t ready = p->chunk_events[(size_t)chunks + (size_t)w];
+            HIP_TRY(hipEventRecord(ready, p->stream));
+            HIP_TRY(hipStreamWaitEvent(out, ready, 0));
+        }
+        while (next_chunk < chunks &&
+               count*(next_chunk + 1)/chunks <= wb) {
+            const long long a = count*next_chunk/chunks,
+                            b = count*(next_chunk + 1)/chunks;
+            HIP_TRY(hipMemcpyAsync(p->h_packed + a*V, p->d_packed + a*V,
+                                   (size_t)(b - a)*V*sizeof(double),
+                                   hipMemcpyDeviceToHost, out));
+            HIP_TRY(hipEventRecord(p->chunk_events[(size_t)next_chunk], out));
+            ++next_chunk;
+        }
     }
     ScatterPool &pool = ScatterPool::instance();
     pool.set_numa_node(host_numa_node(h_blocks));
@@ -1857,23 +1898,41 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     if (int rc = order_streams(p)) return rc;
     HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
                            hipMemcpyHostToDevice, p->stream));
-    if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
-                             p->d_jac, whole(p), true))
-        return rc;
     // `fresh`: the caller's word that `jac` does not hold this handle's
     // invariant entries.  The address alone proves nothing -- a freed block
     // can come back from the allocator at the same address.
     const bool full = fresh != 0 || !p->static_valid ||
                       p->static_host != jac || !packing_pays(p);
+    Producer produce;
+    if (full) {
+        if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
+                                 p->d_jac, whole(p), true))
+            return rc;
+    } else {
+        // evaluated window by window inside move_blocks_to_host; the
+        // instance tails (they read all of `free` and the node-invariant
+        // table the first window fills) behind the last window
+        produce = [p, P, ncn](long long a, long long b) {
+            if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
+                                     p->d_jac + a*P, NodeRange{a, b, ncn},
+                                     false))
+                return rc;
+            if (b == ncn && p->d.num_inst > 0)
+                return launch_instance(p, p->d_free, nullptr,
+                                       p->d_jac + P*ncn);
+            return 0;
+        };
+    }
+    if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full, produce)) {
+        p->static_valid = false;
+        return rc;
+    }
     if (p->d.nnz_inst > 0)
         HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
                                p->d.nnz_inst*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
-    if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full)) {
-        p->static_valid = false;
-        return rc;
-    }
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    if (p->copy_stream) HIP_TRY(hipStreamSynchronize(p->copy_stream));
     p->static_host = jac;
     p->static_valid = true;
     return 0;
@@ -1997,6 +2056,12 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                    double *con, double *jac, int mem, bool full) {
     if (!p->have_segments)
         return fail("the segments were never set (opty_hip_set_segments)");
+    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+    auto now = [] {
+        return std::chrono::duration<double, std::milli>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double t_in = trace ? now() : 0.0;
     const bool want_con = what != OPTY_HIP_EVAL_JAC;
     const long long P = p->P(), ncn = p->ncon_nodes(), N = p->d.N;
     const long long L0 = p->seg_len[0], L1 = p->seg_len[1];
@@ -2033,7 +2098,7 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                                    : 0;
     const size_t head_bytes = (size_t)L0*ncn*sizeof(double);
     int W = want_windows ? want_windows
-                         : (head_bytes >= (32u << 20) ? 6 : 1);
+                         : (head_bytes >= (32u << 20) ? 8 : 1);
     if (p->stream == (hipStream_t)OPTY_HIP_STREAM_LEGACY) W = 1;
     W = (int)std::min<long long>(W, std::max<long long>(1, ncn/64));
     if (W > 1 && !p->copy_stream)
@@ -2057,7 +2122,17 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         p->chunk_events.push_back(e);
     }
-    if (rest > 0)
+    // A page-locked `free` is uploaded window by window (2-D copies of the
+    // trajectory rows); a pageable one -- what a NumPy caller hands over --
+    // in one piece: the runtime stages pageable memory itself, at 55 GB/s
+    // for one long copy and much less for strided ones.
+    const bool by_window = W > 1 &&
+        mapped_address(const_cast<double *>(free_)) != nullptr;
+    if (!by_window)
+        HIP_TRY(hipMemcpyAsync(p->d_free, free_,
+                               (size_t)p->num_free()*sizeof(double),
+                               hipMemcpyHostToDevice, p->stream));
+    else if (rest > 0)
         HIP_TRY(hipMemcpyAsync(p->d_free + rows*N, free_ + rows*N,
                                (size_t)rest*sizeof(double),
                                hipMemcpyHostToDevice, p->stream));
@@ -2067,11 +2142,7 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
         // time nodes [a, b] of every trajectory row (one-node halo; the
         // first column of a later window is there already)
         const long long c0 = w == 0 ? a : a + 1;
-        if (W == 1)
-            HIP_TRY(hipMemcpyAsync(p->d_free, free_,
-                                   (size_t)rows*N*sizeof(double),
-                                   hipMemcpyHostToDevice, p->stream));
-        else
+        if (by_window)
             HIP_TRY(hipMemcpy2DAsync(p->d_free + c0, (size_t)N*sizeof(double),
                                      free_ + c0, (size_t)N*sizeof(double),
                                      (size_t)(b + 1 - c0)*sizeof(double),
@@ -2128,11 +2199,6 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                                p->d_seg + (L0 + L1)*ncn,
                                (size_t)p->seg_len[2]*ncn*sizeof(double),
                                hipMemcpyDeviceToHost, p->stream));
-    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
-    auto now = [] {
-        return std::chrono::duration<double, std::milli>(
-            std::chrono::steady_clock::now().time_since_epoch()).count();
-    };
     const double t0 = trace ? now() : 0.0;
     double t_first = 0.0, t_last = 0.0;
     int rc = 0;
@@ -2164,10 +2230,10 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
     if (W > 1) HIP_TRY(hipStreamSynchronize(out));
     if (trace)
         fprintf(stderr, "opty_hip: segmented, %lld nodes x %lld entries, %d "
-                "windows, %d chunks%s: first chunk landed +%.2f ms after "
-                "enqueue, last +%.2f, all done +%.2f\n", ncn, L0, W, chunks,
-                full ? " (+ invariant segment)" : "", t_first - t0,
-                t_last - t0, now() - t0);
+                "windows, %d chunks%s: enqueued +%.2f ms, first chunk landed "
+                "+%.2f, last +%.2f, all done +%.2f\n", ncn, L0, W, chunks,
+                full ? " (+ invariant segment)" : "", t0 - t_in,
+                t_first - t_in, t_last - t_in, now() - t_in);
     return 0;
 }
 
