@@ -132,6 +132,55 @@ chunk_store(double *out, long long row_doubles, long long nnodes, int nchunk) {
     }
 }
 
+// pattern 4 (r04): PERSISTENT grid, work taken from an atomic ticket in
+// address order.  Ticket t -> node block t / G, strip t % G: the resident
+// waves always cover the lowest unfinished window of the output (R resident
+// workgroups -> a window of about R / G node blocks).  One counter for the
+// chip, or one per XCD (xcd = blockIdx.x % 8 takes the blocks 8k + xcd).
+template <int SEG, bool PER_XCD>
+__global__ void __launch_bounds__(64)
+ticket_store(double *out, long long row_doubles, long long nnodes, int G,
+             unsigned *tickets) {
+    const int lane = threadIdx.x;
+    const long long nblk = (nnodes + 63)/64;
+    const long long row_bytes = row_doubles*8;
+    const long long strip = (row_bytes/G)/SEG*SEG;
+    constexpr int LPN = SEG/16, NPS = 64/LPN;
+    const int sub = lane % LPN, nsel = lane/LPN;
+    const int xcd = blockIdx.x & 7;
+    __shared__ unsigned t_sh;
+    for (;;) {
+        if (lane == 0) t_sh = atomicAdd(tickets + (PER_XCD ? xcd*32 : 0), 1u);
+        __syncthreads();
+        const unsigned t = t_sh;
+        __syncthreads();
+        long long blk = t/G;
+        const int g = (int)(t % G);
+        if (PER_XCD) blk = blk*8 + xcd;
+        if (blk >= nblk) return;
+        const long long node0 = blk*64;
+        const long long s0 = g*strip,
+                        s1 = (g == G - 1) ? row_bytes : s0 + strip;
+        char *base = (char *)out + node0*row_bytes;
+        const long long region = 64*row_bytes;
+        for (long long c = s0; c < s1; c += SEG) {
+#pragma unroll
+            for (int p = 0; p < 64/NPS; ++p) {
+                const int nd = p*NPS + nsel;
+                long long addr = (long long)base + nd*row_bytes + c;
+                long long al = (addr + 127)/128*128 - (long long)base;
+                long long off = al + sub*16;
+                if (node0 + nd < nnodes && off + 16 <= region) {
+                    double2 v = make_double2((double)lane, (double)c);
+                    __builtin_nontemporal_store(v.x, (double *)(base + off));
+                    __builtin_nontemporal_store(v.y,
+                                                (double *)(base + off) + 1);
+                }
+            }
+        }
+    }
+}
+
 // 256-thread workgroups, each streaming its own contiguous region (4 KB per
 // workgroup-instruction)
 __global__ void __launch_bounds__(256)
@@ -247,13 +296,45 @@ int main(int argc, char **argv) {
             printf("chunk-per-block seg%d  %.4f ms %7.0f GB/s (%d blocks)\n", seg, ms, gb/ms*1e3*(nchunk*seg)/(row*8.0), nblk*nchunk);
         }
     }
+    {
+        // r04: ticket-ordered persistent grids (see ticket_store): resident
+        // workgroups R x strips per block G -> window of ~R/G node blocks
+        const long long row = arg_row;
+        const double gb = nnodes*row*8/1e9;
+        unsigned *tickets;
+        CHECK(hipMalloc(&tickets, 8*32*sizeof(unsigned)));
+        for (int per_xcd = 0; per_xcd < 2; ++per_xcd)
+            for (int G : {8, 20, 32, 64, 128})
+                for (int R : {1024, 2048, 4096}) {
+                    if (G > 32 && row < 2000) continue;
+                    auto run = [&] {
+                        CHECK(hipMemsetAsync(tickets, 0,
+                                             8*32*sizeof(unsigned), 0));
+                        if (per_xcd)
+                            hipLaunchKernelGGL((ticket_store<256, true>),
+                                               dim3(R), dim3(64), 0, 0, out,
+                                               row, nnodes, G, tickets);
+                        else
+                            hipLaunchKernelGGL((ticket_store<256, false>),
+                                               dim3(R), dim3(64), 0, 0, out,
+                                               row, nnodes, G, tickets);
+                    };
+                    float ms = time_ms(run);
+                    printf("ticket %s G=%-3d resident=%-4d seg256 nt  %.4f ms"
+                           "  %7.0f GB/s\n", per_xcd ? "per-xcd" : "global ",
+                           G, R, ms, gb/ms*1e3);
+                    fflush(stdout);
+                }
+        CHECK(hipFree(tickets));
+    }
     const long long n2 = nnodes*arg_row/2;
     for (int nb : {512, 2048, 8192}) {
         const long long per_block = (n2 + nb - 1)/nb;
         float ms = time_ms([&] { hipLaunchKernelGGL(contig256, dim3(nb), dim3(256), 0, 0, (double2 *)out, n2, per_block); });
         printf("contig256 blocks=%d (%.0f KB each) %.4f ms %7.0f GB/s\n", nb, per_block*16/1024.0, ms, n2*16/1e9/ms*1e3);
     }
-    for (int S : {1, 64, 1024, 2048}) {
+    // bandwidth against the number of concurrently advancing address streams
+    for (int S : {1, 4, 16, 64, 256, 512, 1024, 2048, 3072, 4096, 8192}) {
         const long long pieces = (n2 + 255)/256;
         const long long per_stream = (pieces + S - 1)/S;
         float ms = time_ms([&] { hipLaunchKernelGGL(strided_fill, dim3((unsigned)(per_stream*S)), dim3(256), 0, 0, (double2 *)out, n2, S); });
