@@ -104,7 +104,13 @@ class EmitOptions(object):
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
-                 cut='even'):
+                 cut='even', con_attach=None):
+        # fused kernel: constraint rows evaluated by the Jacobian wave that
+        # already computes most of their sub-expressions instead of by a
+        # constraint wave of their own (emit_module): None = automatic (blocks
+        # whose arithmetic, not their bytes, sets the pace), 0 / 1 = never /
+        # whenever a row shares at least half of its work with a strip
+        self.con_attach = None if con_attach is None else int(con_attach)
         # where the strips of a node-major block are cut: 'even' = equal
         # entry counts; 'work' = at the line boundaries that make the strips'
         # total evaluation work smallest (_ModuleWriter.group_ranges): a
@@ -217,6 +223,8 @@ class EmitOptions(object):
                 ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
                 ('' if self.con_split == 'work' else ' con_split=count') +
                 ('' if self.cut == 'even' else ' cut=work') +
+                ('' if self.con_attach is None
+                 else ' con_attach=%d' % self.con_attach) +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -1188,6 +1196,86 @@ class _ModuleWriter(object):
         return '\n'.join(src), dict(name='opty_inst', groups=1, lds_bytes=0)
 
 
+#: constraint rows move into a Jacobian wave of the fused kernel when the
+#: block's weighted operations per byte reach this (x 17: one weighted
+#: operation is ~1.75 instructions of 4 cycles on one of 1024 SIMDs, a byte
+#: 1/6 ps of the chip's store stream -- at 1.0 the two sides are even; the
+#: measured kernels run one wave per SIMD and issue at half that rate), and a
+#: row goes to the strip that shares at least this much of its work
+ATTACH_MIN_INTENSITY = 0.5
+ATTACH_MIN_SHARE = 0.5
+ATTACH_LEFTOVER_WEIGHT = 64
+
+
+def _attach_constraint_rows(prog, w, opts, fused_jac, con_sets):
+    """``(rows per Jacobian wave, remaining constraint waves)`` for the fused
+    kernel.
+
+    The constraint rows and the partials of the same equations share most of
+    their sub-expressions (the muscle-driven leg: all constraint rows alone
+    2370 weighted operations, on top of the Jacobian's 4460 only 212).  A
+    store-bound block hides a separate constraint wave behind its stores (and
+    was measured slower with the rows attached: 10-link 0.143 -> 0.153 ms,
+    DESIGN.md 4.4); a block bound by its arithmetic pays for every operation
+    twice.  So for blocks above ``ATTACH_MIN_INTENSITY`` each row moves to
+    the strip that computes at least ``ATTACH_MIN_SHARE`` of it already
+    (greedy, most expensive row first); rows without such a strip keep their
+    constraint waves."""
+    none = [[] for _ in fused_jac]
+    if opts.con_attach == 0 or opts.con_rows_per_wave or not fused_jac or \
+            opts.ablate is not None:
+        return none, con_sets
+    d = prog.dag
+
+    def weight(roots):
+        return sum(_node_weight(d, i) for i in d.reachable(set(roots)))
+
+    rows = [j for rs in con_sets for j in rs]
+    if opts.con_attach is None:
+        work = weight(prog.jac_out) + weight(prog.con_out)
+        nbytes = 8.0*64*(prog.P + prog.M + len(prog.rows))
+        if 17.0*work/nbytes < ATTACH_MIN_INTENSITY:
+            return none, con_sets
+    strip_roots = []
+    for grp in fused_jac:
+        roots = set()
+        for e0, e1 in grp:
+            if e1 > e0:
+                roots |= {prog.jac_out[v % prog.P]
+                          for v in range(e0, w._virtual_end(e1))}
+        strip_roots.append(roots)
+    base = [weight(r) for r in strip_roots]
+    alone = {j: weight([prog.con_out[j]]) for j in rows}
+    attached = [[] for _ in fused_jac]
+    left = []
+    for j in sorted(rows, key=lambda j: -alone[j]):
+        if alone[j] == 0:
+            # a row of constants / inputs: cheapest strip
+            g = min(range(len(base)), key=lambda g: base[g])
+            attached[g].append(j)
+            continue
+        extra = [weight(strip_roots[g] | {prog.con_out[j]}) - base[g]
+                 for g in range(len(fused_jac))]
+        g = min(range(len(extra)), key=lambda g: (extra[g], base[g]))
+        if extra[g] <= (1.0 - ATTACH_MIN_SHARE)*alone[j]:
+            attached[g].append(j)
+            strip_roots[g].add(prog.con_out[j])
+            base[g] += extra[g]
+        else:
+            left.append(j)
+    if not any(attached):
+        return none, con_sets
+    if left and sum(alone[j] for j in left) <= ATTACH_LEFTOVER_WEIGHT:
+        # what is left would be a wave of its own for next to nothing (the
+        # kinematic rows q' - u of a multibody system): cheapest strip
+        g = min(range(len(base)), key=lambda g: base[g])
+        attached[g] += left
+        left = []
+    keep = set(left)
+    remaining = [[j for j in rs if j in keep] for rs in con_sets]
+    return [sorted(a) for a in attached], [rs for rs in remaining if rs]
+
+
 def _fit_one_round(auto_groups, con_waves, node_blocks, live_groups=None):
     """Strip count for a launch of ``node_blocks`` 64-node blocks
     (``auto_groups`` for large launches; never fewer than 60 % of
@@ -1448,7 +1536,7 @@ def emit_module(prog, opts=None, node_blocks=None):
     elif opts.fused_groups is not None:
         fused_jac = w.group_ranges(opts.fused_groups)
     seeds = dict(jac=len(groups), fused=len(fused_jac),
-                 con_waves=len(con_sets), chunk=opts.chunk,
+                 con_waves=len(alone_sets), chunk=opts.chunk,
                  waves=opts.waves, occupancy=opts.occupancy,
                  line_mode=bool(w.line_mode()),
                  live=w.auto_groups()[0] if opts.groups is None else None)
@@ -1457,12 +1545,16 @@ def emit_module(prog, opts=None, node_blocks=None):
             return sum(w._strip_cost(e0, e1) for e0, e1 in grp if e1 > e0)
         groups = sorted(groups, key=work, reverse=True)
         fused_jac = sorted(fused_jac, key=work, reverse=True)
-    con_groups = [[(0, 0)]]*len(con_sets)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
-    # waves ride in the shadow of the store-bound Jacobian waves.
+    # waves ride in the shadow of the store-bound Jacobian waves.  Where the
+    # ARITHMETIC sets the pace instead, a constraint row is evaluated by the
+    # Jacobian wave that computes most of its sub-expressions anyway.
+    attached, con_sets = _attach_constraint_rows(prog, w, opts, fused_jac,
+                                                 con_sets)
+    con_groups = [[(0, 0)]]*len(con_sets)
     fused_groups = list(fused_jac) + con_groups
-    con_of = [[] for _ in fused_jac] + con_sets
+    con_of = attached + con_sets
     parts = []
     kernels = {}
     # Constraint stores.  Written once, never re-read by the kernels: on their
