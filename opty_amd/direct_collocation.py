@@ -648,13 +648,16 @@ class ConstraintCollocator(object):
 
     def prebuild(self):
         """Builds everything :meth:`_ensure_hip` will want, without a device:
-        the code object and, for kernels at the register limit, the ``-O1``
-        twin that :meth:`_verify_build` compares it with.  Returns ``(hsaco,
+        the code object and, for kernels at the register limit, the twins
+        that :meth:`_verify_build` compares it with.  Returns ``(hsaco,
         meta)``."""
         hsaco, meta = self._build_code_object()
         if hb.high_pressure_kernels(hsaco):
             hb.compile_module(self._built_source, self.tmp_dir,
                               self.show_compile_output, opt_level='-O1')
+            hb.compile_module(self._built_source, self.tmp_dir,
+                              self.show_compile_output,
+                              extra_flags=hb.SAFE_SCHEDULER_FLAGS)
         return hsaco, meta
 
     #: nodes the automatic check below evaluates (``OPTY_CROSS_CHECK=off``
@@ -662,22 +665,34 @@ class ConstraintCollocator(object):
     _VERIFY_NODES = 131
 
     def _verify_build(self, hsaco, meta):
-        """Holds a build whose kernels sit at the edge of the register file
+        """Checks a build whose kernels sit at the edge of the register file
         (``hip_backend.high_pressure_kernels``: >= 480 VGPRs or spilled
-        SGPRs) to an ``-O1`` twin of the SAME generated source before the
-        handle is handed out; raises :class:`hip_backend.HipBackendError` on
-        disagreement.
+        SGPRs) before the handle is handed out; raises
+        :class:`hip_backend.HipBackendError` when it cannot be confirmed.
 
-        Why: the wrong, run-to-run different values of round 3 came from
-        ``-O2`` schedules of exactly such kernels (the pre-RA scheduler's
-        high-register-pressure stage); "no vector spills" is a
-        symptom fence, this is the check itself.  Both code objects evaluate
-        the first ``_VERIFY_NODES`` nodes of the problem (two full waves and a
-        ragged one; the kernels do not depend on N, the wrong builds were
-        wrong at every node) -- constraints, Jacobian and the fused launch --
-        on seeded values.  The verdict is remembered next to the code object
-        (``<hsaco>.crosscheck.json``), the twin is cached by source hash like
-        every build (``__graft_entry__.build`` prebuilds it)."""
+        Why: hipcc 7.2 has produced code objects of exactly such kernels
+        whose values are wrong (deterministically, at every node): ``-O2``
+        schedules with vector spills in round 3, and in round
+        4 an ``-O1`` build WITHOUT vector spills (504 VGPRs, 373 spilled
+        SGPRs: the row-sorted Jacobian kernel of the muscle-driven leg, 2.7 %
+        off in one strip).  "No vector spills" is a symptom fence; this is
+        the check itself, a consensus of independently compiled kernels:
+
+        1. the build's own two Jacobian kernels -- ``opty_jac`` and the fused
+           ``opty_conjac``, different cuts of the same expressions compiled
+           separately -- must agree with each other (and its two constraint
+           kernels likewise);
+        2. one kernel of a *twin* -- the SAME generated source through
+           another compiler pipeline: ``-O1``, then ``-O2`` without the
+           scheduler stage implicated in round 3 -- must agree with them.  A
+           twin that disagrees with itself is discarded (it is the faulty
+           one).
+
+        Everything evaluates the first ``_VERIFY_NODES`` nodes of the problem
+        (two full waves and a ragged one; the kernels do not depend on N) on
+        seeded values.  The verdict is remembered next to the code object
+        (``<hsaco>.crosscheck.json``); the twins are cached by source hash
+        like every build (``__graft_entry__.build`` prebuilds the first)."""
         import json
         import os
         if os.environ.get('OPTY_CROSS_CHECK', '').lower() == 'off':
@@ -694,19 +709,45 @@ class ConstraintCollocator(object):
         except (OSError, ValueError):
             pass
         logger.info('kernels %s are at the register limit: checking the '
-                    'build against its -O1 twin', hot)
-        twin = hb.compile_module(self._built_source, self.tmp_dir,
-                                 self.show_compile_output, opt_level='-O1')
-        worst = self._compare_builds(meta, hsaco, twin)
-        verdict = dict(ok=bool(worst <= self._VERIFY_RTOL), worst=worst,
+                    'build', hot)
+        tol = self._VERIFY_RTOL
+        mine = self._evaluate_build(meta, hsaco)
+        own = self._disagreement(mine[:2], mine[2:])
+        verdict = dict(ok=False, own=own, worst=own,
                        kernels={k: list(v) for k, v in hot.items()},
-                       twin=os.path.basename(twin))
+                       twins=[])
+        if own > tol:
+            raise hb.HipBackendError(
+                'the separate and the fused kernels of %s (%s) disagree by '
+                '%.3g relative: a compiler fault (DESIGN.md 4.1).  Rebuild '
+                'with other emit_options or OPTY_HIPCC_OPT=-O1.'
+                % (os.path.basename(hsaco), hot, own))
+        for label, kwargs in (('-O1', dict(opt_level='-O1')),
+                              ('no-hp-reschedule', dict(
+                                  extra_flags=hb.SAFE_SCHEDULER_FLAGS))):
+            twin = hb.compile_module(self._built_source, self.tmp_dir,
+                                     self.show_compile_output, **kwargs)
+            theirs = self._evaluate_build(meta, twin)
+            # each of the twin's kernels against the build's
+            sep = self._disagreement(mine[:2], theirs[:2])
+            fused = self._disagreement(mine[:2], theirs[2:])
+            verdict['twins'].append(dict(
+                build=label, file=os.path.basename(twin), separate=sep,
+                fused=fused, own=self._disagreement(theirs[:2], theirs[2:])))
+            if min(sep, fused) <= tol:
+                verdict.update(ok=True, worst=max(own, min(sep, fused)),
+                               confirmed_by=label)
+                break
+            logger.warning('the %s twin of %s disagrees with it (%.3g / '
+                           '%.3g relative) and with itself by %.3g',
+                           label, os.path.basename(hsaco), sep, fused,
+                           verdict['twins'][-1]['own'])
         if not verdict['ok']:
             raise hb.HipBackendError(
-                'the optimised build of this problem\'s kernels (%s: %s) '
-                'disagrees with its -O1 twin by %.3g relative: a compiler '
-                'fault (DESIGN.md 4.1).  Rebuild with OPTY_HIPCC_OPT=-O1 or '
-                'other emit_options.' % (os.path.basename(hsaco), hot, worst))
+                'no other build of this problem\'s kernels confirms %s (%s): '
+                '%s -- a compiler fault in one of them (DESIGN.md 4.1).  '
+                'Rebuild with other emit_options.'
+                % (os.path.basename(hsaco), hot, verdict['twins']))
         try:
             tmp = side + '.%d.tmp' % os.getpid()
             with open(tmp, 'w') as f:
@@ -718,11 +759,25 @@ class ConstraintCollocator(object):
 
     _VERIFY_RTOL = 1e-9
 
-    def _compare_builds(self, meta, hsaco_a, hsaco_b, seed=7):
-        """Largest disagreement (relative to the largest value of each
-        vector) of two code objects of this problem's module on the first
-        ``_VERIFY_NODES`` nodes: separate and fused launches, host buffers,
-        no instance tails (they are scalar code)."""
+    @staticmethod
+    def _disagreement(xs, ys):
+        """Largest difference of paired vectors relative to the largest value
+        of each pair (inf for non-finite differences)."""
+        worst = 0.0
+        for x, y in zip(xs, ys):
+            if not x.size:
+                continue
+            scale = max(float(np.abs(x).max()), float(np.abs(y).max()),
+                        1e-300)
+            d = np.abs(x - y)
+            worst = max(worst, float(d.max())/scale
+                        if np.isfinite(d).all() else np.inf)
+        return worst
+
+    def _evaluate_build(self, meta, hsaco, seed=7):
+        """``[con, jac, fused con, fused jac]`` of one code object of this
+        problem's module on the first ``_VERIFY_NODES`` nodes: separate and
+        fused launches, host buffers, no instance tails (scalar code)."""
         N = min(self.num_collocation_nodes, self._VERIFY_NODES)
         n, q = self.num_states, self.num_unknown_input_trajectories
         rng = np.random.default_rng(seed)
@@ -734,131 +789,35 @@ class ConstraintCollocator(object):
                     num_inst_atoms=0, inst_folded=0)
         if self._jacobian_layout == 'varying_first':
             desc['layout'] = 0          # the kernels write node-major blocks
-        known = None
-        if self.num_known_input_trajectories:
-            known = np.ascontiguousarray(self._known_trajectory_array(
-                np.ones(self.num_free))[:, :N])
-        outs = []
-        for hsaco in (hsaco_a, hsaco_b):
-            h = hb.HipProblem(desc, hsaco)
-            try:
-                if not self._variable_duration:
-                    h.set_interval(self.node_time_interval)
-                if self.num_known_parameters:
-                    h.set_known_parameters(np.array(
-                        [float(self.known_parameter_map[p])
-                         for p in self.known_parameters]))
-                if known is not None:
-                    h.set_known_trajectories(known)
-                if self._program.pruned or self._jacobian_layout == 'csr':
-                    h.set_block_pattern(self._program.pattern)
-                vecs = []
-                con = np.empty(self.num_eom*(N - 1))
-                jac = np.empty(h.nnz)
-                h.eval_con(free, con, hb.HOST)
-                h.eval_jac(free, jac, hb.HOST)
-                vecs += [con.copy(), jac.copy()]
-                h.eval_con_jac(free, con, jac, hb.HOST)
-                vecs += [con, jac]
-                outs.append(vecs)
-            finally:
-                h.close()
-        worst = 0.0
-        for x, y in zip(*outs):
-            scale = max(float(np.abs(x).max()), 1e-300) if x.size else 1.0
-            if x.size:
-                d = np.abs(x - y)
-                worst = max(worst, float(d.max())/scale
-                            if np.isfinite(d).all() else np.inf)
-        return worst
-
-
-    def tune_launch(self, **kwargs):
-        """Times the neighbouring launch geometries of this problem on the
-        device, records the winners in the launch-plan file
-        (:mod:`opty_amd.launch_plan`) and rebuilds this collocator's kernels
-        with them.  Returns the plan entry."""
-        from . import launch_plan
-        entry = launch_plan.tune(self, **kwargs)
-        if self._hip is not None:
-            self._hip.close()
-        self._hip = None
-        if kwargs.get('save', True):
-            # the recorded plan is what the next build looks up; options the
-            # caller fixed stay in force when nothing was recorded
-            self._emit_options = None
-        return entry
-
-    def cross_check(self, free=None, window=4096, opt_level='-O1'):
-        """Evaluates this problem's kernels twice -- the build in use and a
-        build of the SAME generated module that went through another compiler
-        pipeline (``hipcc -O1``) -- on the same ``free`` (default: seeded
-        random values) and returns the largest disagreement of constraints
-        and Jacobian values over the first and last ``window`` constraint
-        nodes, relative to the largest value of each vector (rounding level,
-        ~1e-15, when both builds are right).
-
-        Why: kernels at the register limit (50-state systems) met an ``-O2``
-        miscompile of the pre-register-allocation scheduler in round 3
-        (DESIGN.md section 4.1).  Builds with its symptom -- vector-register
-        spills -- are never used, and the shipped configurations are tested
-        against the reference; this is the same check for a problem of your
-        own, once, after the first build (the ``-O1`` twin of a 50-state
-        system takes a minute or two to compile).  Needs ``torch``."""
-        import torch
-        hip = self._ensure_hip()
-        meta = self._kernel_meta
-        hsaco = hb.compile_module(self._built_source, self.tmp_dir,
-                                  self.show_compile_output,
-                                  opt_level=opt_level)
-        twin = hb.HipProblem(self._descriptor(meta), hsaco)
+        h = hb.HipProblem(desc, hsaco)
         try:
-            self._install_tables(twin)
-            if free is None:
-                free = np.random.default_rng(7).uniform(-1.0, 1.0,
-                                                        self.num_free)
-                if self._variable_duration:
-                    free[-1] = 0.01
-            free = self._host_free(free)
-            self._sync_known(hip, free)
-            self._uploaded_parameters = self._uploaded_trajectories = None
-            self._sync_known(twin, free)
-            if self._jacobian_layout != 'coo':
-                # the row-sorted layout is not evaluated by node ranges
-                outs = []
-                for h in (hip, twin):
-                    con = np.empty(self.num_constraints)
-                    jac = np.empty(h.nnz)
-                    h.eval_con_jac(free, con, jac, hb.HOST)
-                    outs.append((con, jac))
-                return max(float(np.abs(x - y).max()) /
-                           max(float(np.abs(x).max()), 1e-300)
-                           for x, y in zip(*outs))
-            dev = torch.device('cuda', self._device)
-            ncn = self.num_collocation_nodes - 1
-            w = max(1, min(int(window), ncn))
-            windows = sorted({(0, w), (ncn - w, ncn)})
-            P, M = self._program.P, self.num_eom
-            d_free = torch.from_numpy(free).to(dev)
-            worst = 0.0
-            for a, b in windows:
-                outs = []
-                for h in (hip, twin):
-                    con = torch.empty((M, b - a), dtype=torch.float64,
-                                      device=dev)
-                    jac = torch.empty((b - a)*P, dtype=torch.float64,
-                                      device=dev)
-                    h.eval_shard(hb.EVAL_FUSED, d_free, con, b - a, jac, a, b)
-                    h.synchronize()
-                    outs.append((con.cpu().numpy(), jac.cpu().numpy()))
-                for x, y in zip(*outs):
-                    scale = max(float(np.abs(x).max()), 1e-300)
-                    worst = max(worst, float(np.abs(x - y).max())/scale)
-            return worst
+            if not self._variable_duration:
+                h.set_interval(self.node_time_interval)
+            if self.num_known_parameters:
+                h.set_known_parameters(np.array(
+                    [float(self.known_parameter_map[p])
+                     for p in self.known_parameters]))
+            if self.num_known_input_trajectories:
+                h.set_known_trajectories(np.ascontiguousarray(
+                    self._known_trajectory_array(
+                        np.ones(self.num_free))[:, :N]))
+            if self._program.pruned or self._jacobian_layout == 'csr':
+                h.set_block_pattern(self._program.pattern)
+            con = np.empty(self.num_eom*(N - 1))
+            jac = np.empty(h.nnz)
+            h.eval_con(free, con, hb.HOST)
+            h.eval_jac(free, jac, hb.HOST)
+            con2, jac2 = np.empty_like(con), np.empty_like(jac)
+            h.eval_con_jac(free, con2, jac2, hb.HOST)
+            return [con, jac, con2, jac2]
         finally:
-            twin.close()
-            # the upload cache belongs to the handle in use
-            self._uploaded_parameters = self._uploaded_trajectories = None
+            h.close()
+
+    def _compare_builds(self, meta, hsaco_a, hsaco_b, seed=7):
+        """Largest disagreement of two code objects of this problem's module
+        (kernel by kernel) on the first ``_VERIFY_NODES`` nodes."""
+        return self._disagreement(self._evaluate_build(meta, hsaco_a, seed),
+                                  self._evaluate_build(meta, hsaco_b, seed))
 
     def _descriptor(self, meta):
         prog = self._program

@@ -845,18 +845,21 @@ def test_persistent_jacobian_does_not_trust_a_reused_address():
 
 
 def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
-    """``_verify_build``: a build at the register limit is compared with its
-    ``-O1`` twin before the handle exists.  The real pair agrees (verdict
-    remembered next to the code object); a twin that computes something else
-    -- here: the module of slightly different equations, standing in for a
-    miscompiled build -- makes the constructor path raise."""
+    """``_verify_build``: a build at the register limit is confirmed by a
+    consensus of independently compiled kernels before the handle exists --
+    its own separate and fused kernels, then a twin of the same source from
+    another compiler pipeline.  The real build passes (verdict remembered
+    next to the code object); a faulty TWIN is outvoted by the next one; a
+    build that computes something else -- here: the module of slightly
+    different equations, standing in for a miscompiled one -- is refused."""
     import opty_amd
     from opty_amd import hip_backend as hb
     kw = problems.build('one_legged_small')
     col = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path), **kw)
     hip = col.hip                      # builds, verifies, creates the handle
-    assert col._build_verdict['ok'] and col._build_verdict['worst'] < 1e-12
-    assert 'opty_conjac' in col._build_verdict['kernels']
+    verdict = col._build_verdict
+    assert verdict['ok'] and verdict['worst'] < 1e-12, verdict
+    assert 'opty_conjac' in verdict['kernels']
     hsaco = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
     assert any(os.path.exists(os.path.join(tmp_path, f + '.crosscheck.json'))
                for f in hsaco)
@@ -868,20 +871,52 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
         **dict(kw, equations_of_motion=eom.applyfunc(
             lambda e: e*(1 + 2.0**-20))))
     bad, _ = wrong._build_code_object()
-    col2 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'second'),
-                                         **kw)
     real = hb.compile_module
 
-    def twin_is_wrong(source, *args, **kwargs):
+    # (1) the -O1 twin is the faulty one: the second twin confirms the build
+    def o1_is_wrong(source, *args, **kwargs):
         if kwargs.get('opt_level') == '-O1':
             return bad
         return real(source, *args, **kwargs)
-    monkeypatch.setattr(hb, 'compile_module', twin_is_wrong)
-    with pytest.raises(hb.HipBackendError, match='disagrees'):
-        col2.hip
+    monkeypatch.setattr(hb, 'compile_module', o1_is_wrong)
+    col2 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'second'),
+                                         **kw)
+    assert col2.hip is not None
+    assert col2._build_verdict['confirmed_by'] == 'no-hp-reschedule'
+    assert col2._build_verdict['twins'][0]['separate'] > 1e-9
+    col2.hip.close()
+    # (2) the build in use is the faulty one: no twin confirms it
     monkeypatch.setattr(hb, 'compile_module', real)
+    col3 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'third'), **kw)
+    good, meta = col3._build_code_object()
+    source = col3._built_source
+
+    def faulty_build(opt_level=None):
+        col3._built_source = source
+        return bad, meta
+    monkeypatch.setattr(col3, '_build_code_object', faulty_build)
+    with pytest.raises(hb.HipBackendError, match='confirms'):
+        col3.hip
     monkeypatch.setenv('OPTY_CROSS_CHECK', 'off')
-    assert col2.hip is not None          # the documented opt-out
+    assert col3.hip is not None          # the documented opt-out
+
+
+def test_row_sorted_muscle_model_o1_twin_is_the_faulty_one():
+    """Round 4's find, kept as a regression test of the CHECK (not of the
+    compiler): the ``-O1`` build of the row-sorted module of the
+    muscle-driven leg has a Jacobian kernel that is 2.7 % off WITHOUT
+    spilling vector registers; the build in use is right and is confirmed --
+    by whichever twin agrees -- and matches the reference."""
+    import opty_amd
+    kw = problems.build('one_legged_small')
+    col = opty_amd.ConstraintCollocator(jacobian_layout='csr', **kw)
+    col.hip
+    verdict = col._build_verdict
+    assert verdict['ok'] and verdict['own'] < 1e-12, verdict
+    for twin in verdict['twins']:
+        # a twin that does not confirm the build disagrees with ITSELF
+        if min(twin['separate'], twin['fused']) > 1e-9:
+            assert twin['own'] > 1e-9, verdict
 
 
 @pytest.mark.gpu

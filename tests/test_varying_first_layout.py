@@ -124,9 +124,10 @@ def test_triplet_set_equals_the_reference(name, windows, monkeypatch):
     np.testing.assert_allclose(dv[:L0*N1], vals[:L0*N1], **close)
     np.testing.assert_allclose(dv, vals, rtol=1e-9, atol=1e-11*max(
         1.0, np.abs(vals).max()))
+    # (the fused kernel's constraint rows against the separate kernel's)
     np.testing.assert_allclose(
         dcon.cpu().numpy(), ref.generate_constraint_function()(z['free']),
-        rtol=1e-12, atol=1e-12)
+        rtol=1e-10, atol=1e-10)
 
 
 @pytest.mark.gpu
