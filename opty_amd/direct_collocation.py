@@ -819,6 +819,93 @@ class ConstraintCollocator(object):
         return self._disagreement(self._evaluate_build(meta, hsaco_a, seed),
                                   self._evaluate_build(meta, hsaco_b, seed))
 
+    def tune_launch(self, **kwargs):
+        """Times the neighbouring launch geometries of this problem on the
+        device, records the winners in the launch-plan file
+        (:mod:`opty_amd.launch_plan`) and rebuilds this collocator's kernels
+        with them.  Returns the plan entry."""
+        from . import launch_plan
+        entry = launch_plan.tune(self, **kwargs)
+        if self._hip is not None:
+            self._hip.close()
+        self._hip = None
+        if kwargs.get('save', True):
+            # the recorded plan is what the next build looks up; options the
+            # caller fixed stay in force when nothing was recorded
+            self._emit_options = None
+        return entry
+
+    def cross_check(self, free=None, window=4096, opt_level='-O1'):
+        """Evaluates this problem's kernels twice -- the build in use and a
+        build of the SAME generated module that went through another compiler
+        pipeline (``hipcc -O1``) -- on the same ``free`` (default: seeded
+        random values) and returns the largest disagreement of constraints
+        and Jacobian values over the first and last ``window`` constraint
+        nodes, relative to the largest value of each vector (rounding level,
+        ~1e-15, when both builds are right).
+
+        Why: kernels at the register limit (50-state systems) met an ``-O2``
+        miscompile of the pre-register-allocation scheduler in round 3
+        (DESIGN.md section 4.1).  Builds with its symptom -- vector-register
+        spills -- are never used, and the shipped configurations are tested
+        against the reference; this is the same check for a problem of your
+        own, once, after the first build (the ``-O1`` twin of a 50-state
+        system takes a minute or two to compile).  Needs ``torch``."""
+        import torch
+        hip = self._ensure_hip()
+        meta = self._kernel_meta
+        hsaco = hb.compile_module(self._built_source, self.tmp_dir,
+                                  self.show_compile_output,
+                                  opt_level=opt_level)
+        twin = hb.HipProblem(self._descriptor(meta), hsaco)
+        try:
+            self._install_tables(twin)
+            if free is None:
+                free = np.random.default_rng(7).uniform(-1.0, 1.0,
+                                                        self.num_free)
+                if self._variable_duration:
+                    free[-1] = 0.01
+            free = self._host_free(free)
+            self._sync_known(hip, free)
+            self._uploaded_parameters = self._uploaded_trajectories = None
+            self._sync_known(twin, free)
+            if self._jacobian_layout != 'coo':
+                # the row-sorted layout is not evaluated by node ranges
+                outs = []
+                for h in (hip, twin):
+                    con = np.empty(self.num_constraints)
+                    jac = np.empty(h.nnz)
+                    h.eval_con_jac(free, con, jac, hb.HOST)
+                    outs.append((con, jac))
+                return max(float(np.abs(x - y).max()) /
+                           max(float(np.abs(x).max()), 1e-300)
+                           for x, y in zip(*outs))
+            dev = torch.device('cuda', self._device)
+            ncn = self.num_collocation_nodes - 1
+            w = max(1, min(int(window), ncn))
+            windows = sorted({(0, w), (ncn - w, ncn)})
+            P, M = self._program.P, self.num_eom
+            d_free = torch.from_numpy(free).to(dev)
+            worst = 0.0
+            for a, b in windows:
+                outs = []
+                for h in (hip, twin):
+                    con = torch.empty((M, b - a), dtype=torch.float64,
+                                      device=dev)
+                    jac = torch.empty((b - a)*P, dtype=torch.float64,
+                                      device=dev)
+                    h.eval_shard(hb.EVAL_FUSED, d_free, con, b - a, jac, a, b)
+                    h.synchronize()
+                    outs.append((con.cpu().numpy(), jac.cpu().numpy()))
+                for x, y in zip(*outs):
+                    scale = max(float(np.abs(x).max()), 1e-300)
+                    worst = max(worst, float(np.abs(x - y).max())/scale)
+            return worst
+        finally:
+            twin.close()
+            # the upload cache belongs to the handle in use
+            self._uploaded_parameters = self._uploaded_trajectories = None
+
     def _descriptor(self, meta):
         prog = self._program
         return dict(
