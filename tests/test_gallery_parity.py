@@ -168,3 +168,52 @@ def test_gallery_hip(name):
     jac2 = hb.pinned_empty(len(jac))
     col.hip.eval_con_jac(z['free'], con2, jac2, hb.HOST)
     _check_values(meta, z, col, con2, jac2, name + ' fused')
+
+
+#: constraint nodes of the scaled runs: 23 full waves and a ragged one
+SCALED_NODES = 1501
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [k for k in gc.NAMES
+                                  if k not in ORACLE_HEAVY])
+def test_gallery_scaled_against_oracle(name):
+    """The same problems on ``SCALED_NODES`` collocation nodes (duration
+    kept, instance times moved with the grid, known trajectories
+    interpolated: ``gallery_cases.rescale``) -- several node blocks, a ragged
+    last wave, strips and windows the recorded sizes do not reach -- against
+    the oracle (which the recorded sizes pin to the reference)."""
+    import opty_amd
+    from oracle.collocation_oracle import OracleCollocator
+    from examples import problems
+    meta, z, kw = gc.load(name)
+    kw = gc.rescale(kw, SCALED_NODES)
+    col = opty_amd.ConstraintCollocator(**kw)
+    orc = OracleCollocator(name=name, **kw)
+    vd = col._variable_duration
+    free = problems.make_free(col.num_free, seed=11, variable_duration=vd)
+    if vd:
+        free[-1] = z['free'][-1]
+    c_ref = orc.generate_constraint_function()(free)
+    j_ref = np.asarray(orc.generate_jacobian_function()(free))
+    assert np.isfinite(c_ref).all() and np.isfinite(j_ref).all()
+    r_ref, k_ref = orc.jacobian_indices()
+    base = col.num_eom*col.num_block_columns*(SCALED_NODES - 1)
+    order = base + np.lexsort((k_ref[base:], r_ref[base:]))
+    r_ref[base:], k_ref[base:], j_ref[base:] = (r_ref[order], k_ref[order],
+                                                j_ref[order])
+    con = col.generate_constraint_function()(free)
+    jac = col.generate_jacobian_function()(free)
+    rows, cols = col.jacobian_indices()
+    np.testing.assert_array_equal(rows, r_ref)
+    np.testing.assert_array_equal(cols, k_ref)
+    cb, jb = gu.error_bounds(col, free)
+    N1, M, C = SCALED_NODES - 1, col.num_eom, col.num_block_columns
+    ccap, jcap = gu.row_caps(j_ref[:N1*M*C].reshape(N1, M, C))
+    ccap = np.concatenate((ccap.ravel(), np.full(len(con) - N1*M, np.inf)))
+    jcap = np.concatenate((jcap.ravel(),
+                           np.full(len(jac) - N1*M*C, np.inf)))
+    gu.assert_close(con, c_ref, RTOL, what=name + ' scaled con', bound=cb,
+                    cap=ccap)
+    gu.assert_close(jac, j_ref, RTOL, what=name + ' scaled jac', bound=jb,
+                    cap=jcap)
