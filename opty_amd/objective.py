@@ -214,6 +214,20 @@ def build_objective_program(objective, state_symbols,
     return dag, (g_quad, dp_quad, dz_node, b_val, db_val), n, q, r
 
 
+def compile_objective(objective, state_symbols, unknown_input_trajectories,
+                      unknown_parameters, num_collocation_nodes,
+                      integration_method='backward euler', time_symbol=None,
+                      tmp_dir=None):
+    """Lowers, prints and builds the objective kernels (no device needed):
+    ``(code object path, (n, q, r))``."""
+    dag, roots, n, q, r = build_objective_program(
+        objective, state_symbols, unknown_input_trajectories,
+        unknown_parameters, integration_method, time_symbol)
+    source = _emit(dag, n + q, r, int(num_collocation_nodes),
+                   integration_method, roots)
+    return hb.compile_module(source, tmp_dir), (n, q, r)
+
+
 def create_objective_function(objective, state_symbols,
                               unknown_input_trajectories, unknown_parameters,
                               num_collocation_nodes, node_time_interval,
@@ -227,12 +241,11 @@ def create_objective_function(objective, state_symbols,
     Both callables also accept a ``torch`` CUDA tensor for ``free``;
     ``obj_grad`` then returns a CUDA tensor (nothing crosses PCIe).
     """
-    dag, roots, n, q, r = build_objective_program(
+    hsaco, (n, q, r) = compile_objective(
         objective, state_symbols, unknown_input_trajectories,
-        unknown_parameters, integration_method, time_symbol)
+        unknown_parameters, num_collocation_nodes, integration_method,
+        time_symbol, tmp_dir)
     N = int(num_collocation_nodes)
-    source = _emit(dag, n + q, r, N, integration_method, roots)
-    hsaco = hb.compile_module(source, tmp_dir)
     handle = hb.HipObjective(dict(N=N, n=n, q=q, r=r, device=int(device),
                                   h=float(node_time_interval)), hsaco)
     num_free = (n + q)*N + r

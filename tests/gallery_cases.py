@@ -66,6 +66,44 @@ def load(name):
     return meta, z, kwargs
 
 
+def facade(name):
+    """Bounds of the script's ``Problem`` and what the reference made of
+    them: ``(bounds, eom_bounds, expected arrays)``; ``bounds`` values are
+    per-node arrays (a scalar bound is recorded broadcast)."""
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    keys = sympy_codec.decode(json.loads(str(z['bounds_keys'])))
+    bounds = {k: (np.array(lo), np.array(hi))
+              for k, lo, hi in zip(keys, z['bounds_lo'], z['bounds_hi'])}
+    eom_bounds = {int(k): (float(lo), float(hi))
+                  for k, lo, hi in z['eom_bounds']}
+    expected = {k: z[k] for k in ('lower_bound', 'upper_bound', 'low_con',
+                                  'upp_con')}
+    return bounds, (eom_bounds or None), expected
+
+
+def objective(name):
+    """Arguments of the script's ``create_objective_function`` call (as the
+    reference's signature takes them) and the reference's value / gradient at
+    the fixture's ``free``; None when the script wrote its objective by
+    hand."""
+    if not MANIFEST[name].get('has_objective'):
+        return None
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    objs = sympy_codec.decode(json.loads(str(z['objective'])))
+    n, q, r, N = (int(v) for v in z['objective_layout'])
+    expr, rest = objs[0], objs[1:]
+    args = dict(objective=expr, state_symbols=tuple(rest[:n]),
+                unknown_input_trajectories=tuple(rest[n:n + q]),
+                unknown_parameters=tuple(rest[n + q:n + q + r]),
+                num_collocation_nodes=N,
+                node_time_interval=float(z['objective_interval'][0]),
+                integration_method=str(z['objective_method']),
+                time_symbol=rest[n + q + r])
+    num = (n + q)*N + r
+    return args, z['free'][:num], float(z['objective_value'][0]), \
+        z['objective_grad']
+
+
 def rescale(kwargs, num_nodes):
     """The same problem on ``num_nodes`` collocation nodes (full-size bench /
     parity workloads from a gallery problem): the duration is kept for a

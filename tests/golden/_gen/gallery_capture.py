@@ -97,6 +97,25 @@ def _child(stem):
             self._captured_guess = np.array(vector, dtype=float)
         raise _Stop()
 
+    # objectives built by the reference's own helper are recorded too
+    # (opty/utils.py:329: 9 of the scripts use it)
+    import opty.utils as ou
+    ref_cof = ou.create_objective_function
+    cof_sig = inspect.signature(ref_cof)
+    objectives = []
+
+    def cof(*args, **kwargs):
+        bound = cof_sig.bind(*args, **kwargs)
+        bound.apply_defaults()
+        out = ref_cof(*args, **kwargs)
+        objectives.append((dict(bound.arguments), out))
+        return out
+
+    ou.create_objective_function = cof
+    opty.create_objective_function = cof
+    if hasattr(dc, 'create_objective_function'):
+        dc.create_objective_function = cof
+
     RefProblem.__init__ = init
     for name in ('solve', 'plot_trajectories', 'plot_constraint_violations',
                  'plot_objective_value', 'plot_jacobian_sparsity'):
@@ -191,6 +210,61 @@ def _child(stem):
         interval_is_symbol=isinstance(interval, sm.Basic),
         has_time_symbol=True)
 
+    # -- the NLP facade's bound arrays (opty/direct_collocation.py:370-440) --
+    extra = {}
+    bounds = a.get('bounds') or {}
+    eom_bounds = a.get('eom_bounds') or {}
+    bound_keys = list(bounds.keys())
+    extra['bounds_lo'] = np.array([np.broadcast_to(
+        np.asarray(bounds[k][0], dtype=float), (N,)) for k in bound_keys]) \
+        if bound_keys else np.zeros((0, N))
+    extra['bounds_hi'] = np.array([np.broadcast_to(
+        np.asarray(bounds[k][1], dtype=float), (N,)) for k in bound_keys]) \
+        if bound_keys else np.zeros((0, N))
+    extra['eom_bounds'] = np.array([[float(k), float(v[0]), float(v[1])]
+                                    for k, v in eom_bounds.items()]) \
+        if eom_bounds else np.zeros((0, 3))
+    extra['lower_bound'] = np.asarray(prob.lower_bound, dtype=float)
+    extra['upper_bound'] = np.asarray(prob.upper_bound, dtype=float)
+    extra['low_con'] = np.asarray(prob._low_con_bounds, dtype=float)
+    extra['upp_con'] = np.asarray(prob._upp_con_bounds, dtype=float)
+    bounds_blob = sympy_codec.encode(bound_keys)
+    assert sympy_codec.decode(json.loads(json.dumps(bounds_blob))) == \
+        [sm.sympify(k) for k in bound_keys]
+    extra['bounds_keys'] = np.array(json.dumps(bounds_blob))
+
+    # -- the objective, when the script built it with the reference's helper -
+    has_objective = False
+    for oargs, (obj_f, grad_f) in objectives:
+        if prob.obj is not obj_f:
+            continue
+        h_obj = oargs['node_time_interval']
+        if isinstance(h_obj, sm.Basic):
+            break                       # (not evaluable in the reference)
+        oexprs = [sm.sympify(oargs['objective'])]
+        groups = [list(oargs['state_symbols']),
+                  list(oargs['unknown_input_trajectories']),
+                  list(oargs['unknown_parameters'])]
+        for g in groups:
+            oexprs += g
+        oexprs += [oargs['time_symbol']]
+        oblob = sympy_codec.encode(oexprs)
+        oback = sympy_codec.decode(json.loads(json.dumps(oblob)))
+        assert all(sm.sympify(x) == y for x, y in zip(oexprs, oback))
+        n_obj = (len(groups[0]) + len(groups[1]))*int(
+            oargs['num_collocation_nodes']) + len(groups[2])
+        ofree = free[:n_obj]
+        extra['objective'] = np.array(json.dumps(oblob))
+        extra['objective_layout'] = np.array(
+            [len(g) for g in groups] +
+            [int(oargs['num_collocation_nodes'])])
+        extra['objective_interval'] = np.array([float(h_obj)])
+        extra['objective_method'] = np.array(oargs['integration_method'])
+        extra['objective_value'] = np.array([float(obj_f(ofree))])
+        extra['objective_grad'] = np.asarray(grad_f(ofree), dtype=float)
+        has_objective = True
+        break
+
     meta = dict(
         name='gallery_' + stem[5:], script=os.path.relpath(path,
                                                             '/root/reference'),
@@ -200,6 +274,8 @@ def _child(stem):
         nnz=int(len(rows)), nnz_inst=int(len(rows) - base),
         method=col.integration_method, free_recipe=recipe,
         callable_known=callable_known, layout=layout,
+        has_objective=has_objective, num_bounds=len(bound_keys),
+        num_eom_bounds=len(eom_bounds),
         states=[str(x) for x in col.state_symbols],
         known_parameters=[str(x) for x in col.known_parameters],
         unknown_parameters=[str(x) for x in col.unknown_parameters],
@@ -217,7 +293,7 @@ def _child(stem):
                      else np.zeros((0, N))),
         interval=np.array([0.0 if layout['interval_is_symbol']
                            else float(interval)]),
-        problem=np.array(json.dumps(blob)))
+        problem=np.array(json.dumps(blob)), **extra)
     if len(jv) <= FULL_MAX_NNZ:
         arrays.update(con=cv, jac=jv, rows=rows, cols=cols)
         meta['kind'] = 'full'

@@ -217,3 +217,48 @@ def test_gallery_scaled_against_oracle(name):
                     cap=ccap)
     gu.assert_close(jac, j_ref, RTOL, what=name + ' scaled jac', bound=jb,
                     cap=jcap)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', gc.NAMES)
+def test_gallery_problem_facade(name):
+    """``opty_amd.Problem`` built as the script builds the reference's:
+    the variable and constraint bound arrays IPOPT is handed
+    (``opty/direct_collocation.py:370-440``) are the reference's, bit for bit
+    (scalar, per-node and ``eom_bounds`` bounds: 23 of the scripts set
+    some), and the callbacks return what the collocator returns."""
+    import opty_amd
+    meta, z, kw = gc.load(name)
+    bounds, eom_bounds, want = gc.facade(name)
+    prob = opty_amd.Problem(lambda free: 0.0, lambda free: free,
+                            bounds=bounds, eom_bounds=eom_bounds, **kw)
+    assert prob.num_free == meta['num_free']
+    assert prob.num_constraints == meta['num_constraints']
+    np.testing.assert_array_equal(prob.lower_bound, want['lower_bound'])
+    np.testing.assert_array_equal(prob.upper_bound, want['upper_bound'])
+    np.testing.assert_array_equal(prob._low_con_bounds, want['low_con'])
+    np.testing.assert_array_equal(prob._upp_con_bounds, want['upp_con'])
+    rows, cols = prob.jacobianstructure()
+    _check_indices(meta, z, rows, cols)
+    _check_values(meta, z, prob.collocator, prob.constraints(z['free']),
+                  prob.jacobian(z['free']), name + ' facade')
+
+
+OBJECTIVES = [k for k in gc.NAMES if gc.MANIFEST[k].get('has_objective')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', OBJECTIVES)
+def test_gallery_objective(name):
+    """The objectives the scripts build with ``create_objective_function``
+    (``opty/utils.py:329-470``), on the device: value and gradient against
+    what the reference's lambdified functions returned."""
+    import opty_amd
+    args, free, value, grad = gc.objective(name)
+    obj, obj_grad = opty_amd.create_objective_function(**args)
+    got = obj(free)
+    assert abs(got - value) <= 1e-12*max(1.0, abs(value)), (got, value)
+    g = obj_grad(free)
+    assert g.shape == grad.shape
+    np.testing.assert_allclose(g, grad, rtol=1e-12,
+                               atol=1e-13*max(1.0, np.abs(grad).max()))
