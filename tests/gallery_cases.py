@@ -72,7 +72,10 @@ def facade(name):
     per-node arrays (a scalar bound is recorded broadcast)."""
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     keys = sympy_codec.decode(json.loads(str(z['bounds_keys'])))
-    bounds = {k: (np.array(lo), np.array(hi))
+    # (recorded broadcast to N values: a parameter or the node time interval
+    # has one slot)
+    bounds = {k: ((np.array(lo), np.array(hi)) if k.args
+                  else (float(lo[0]), float(hi[0])))
               for k, lo, hi in zip(keys, z['bounds_lo'], z['bounds_hi'])}
     eom_bounds = {int(k): (float(lo), float(hi))
                   for k, lo, hi in z['eom_bounds']}
