@@ -603,6 +603,77 @@ def main():
         if strong or world == 1:
             check_sums(con, jac2d, 'benched launch')
 
+    def headline(extras, verify):
+        """The JSON line (rank 0)."""
+        cnt = b - a
+        free_bytes = 8.0*((col.num_states +
+                           col.num_unknown_input_trajectories)*(cnt + 1))
+        # algorithmic bytes of one launch (SURVEY.md 8(d)): read the free
+        # columns of the launch's nodes once, write the outputs once
+        jac_bytes = free_bytes + 8.0*P*cnt
+        con_bytes = free_bytes + 8.0*M*cnt
+        if args.serial:
+            dom, dom_ms, dom_bytes = 'opty_jac', jac_ms, jac_bytes
+        else:
+            dom, dom_ms = 'opty_conjac', fused_ms
+            dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
+        achieved = dom_bytes/(dom_ms*1e-3)/1e9
+        kmeta = col._kernel_meta['kernels'][
+            'jac' if args.serial else 'conjac']
+        traffic = lookup_traffic(kmeta['sha']) \
+            if (world == 1 and args.nodes == 100000) else None
+        value = args.steps*(1 if strong else world)/elapsed
+        nnz_total = P*(N - 1)*(1 if strong else world)
+        out = {
+            'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
+                      '(10-link pendulum on cart, backward Euler)',
+            'value': value, 'unit': 'evals/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3*elapsed/args.steps,
+            'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': (
+                    '10-link inverted pendulum on cart, %d nodes%s, backward '
+                    'Euler, n=M=22, q=1, C=45, nnz=%d' % (
+                        N, ' per GPU' if not strong else
+                        (' sharded over %d GPUs (BASELINE config 4)' % world
+                         if world > 1 else ''), nnz_total)),
+                'step': ('constraints then Jacobian, two launches'
+                         if args.serial else
+                         'constraints and Jacobian of one free vector from '
+                         'one launch (opty_hip_eval_shard / '
+                         'opty_hip_eval_con_jac)'),
+                'sharding': (
+                    'ONE problem, constraint nodes [%d, %d) of %d on rank 0 '
+                    '(contiguous ranges, one-node halo); outputs left '
+                    'distributed, no data-path collective' % (a, b, N - 1)
+                    if strong else
+                    'independent %d-node problems, one per GPU' % N),
+                'oversubscribed': bool(oversub),
+                'prewarm_ms': args.prewarm_ms,
+                'code_object_sha': col._kernel_meta['sha'][:16],
+                'kernel_sha': kmeta['sha'][:16],
+                'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
+                hip.desc['jac_waves_per_wg'],
+                'GBps_nnz_written': 8.0*P*cnt/(jac_ms*1e-3)/1e9,
+                'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
+                              'opty_conjac': fused_ms},
+                'nodes_per_launch': cnt,
+            },
+            'roofline': {
+                'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
+                'algorithmic_bytes_per_launch': dom_bytes,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
+        }
+        out['config'].update(extras)
+        out['config']['verify'] = verify
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.nodes)
+        return out
+
     extras = {}
     if not args.no_extras:
         if not args.serial:
@@ -610,6 +681,39 @@ def main():
             extras['serial_evals_per_s'] = args.steps*(
                 1 if strong else world)/el
         if world > 1 and strong:
+            # The re-assembly variants are secondary figures, and the only
+            # part of this program that exchanges data between ranks: if they
+            # hang on a node this build has never seen (RCCL point-to-point
+            # over xGMI, eight processes page-locking one mapping), the
+            # headline line -- already measured and verified -- must still
+            # appear.  A watchdog prints it from rank 0 and ends every rank.
+            import threading
+            limit = float(os.environ.get('OPTY_BENCH_VARIANTS_TIMEOUT',
+                                         '240'))
+
+            def give_up():
+                if rank == 0:
+                    local = {
+                        'ok': bool(verifier is None or
+                                   (not verifier.failed and
+                                    verifier.worst <= 1e-10)),
+                        'worst_rel': None if verifier is None
+                        else verifier.worst, 'ranks': world,
+                        'backend': dist.get_backend(),
+                        'checked': [] if verifier is None
+                        else verifier.checked,
+                        'failed': [] if verifier is None else verifier.failed,
+                        'note': 'rank 0 only: the run was ended by the '
+                                'watchdog before the verdicts were reduced'}
+                    extras['variants_error'] = (
+                        'watchdog: the re-assembly variants did not finish '
+                        'within %.0f s' % limit)
+                    print(json.dumps(headline(extras, local)), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(limit + (0.0 if rank == 0 else 10.0),
+                                       give_up)
+            watchdog.daemon = True
+            watchdog.start()
             try:
                 # re-assembly variants of SURVEY.md 8(e); rank 0 is where IPOPT
                 # would run and evaluates its own shard in place
@@ -708,6 +812,9 @@ def main():
                 extras['variants'] = variants
             except Exception as err:      # the headline line must survive
                 extras['variants_error'] = repr(err)
+            # (the watchdog stays armed until the verdicts below are reduced:
+            # a rank that left the variants early must not wait for ever for
+            # one that hangs in them)
         if world == 1:
             extras['other_configs'] = other_configs(dev, max(20,
                                                              args.steps//4))
@@ -729,76 +836,11 @@ def main():
             'golden': 'tests/golden/%s.npz (reference: %s)' % (
                 WORKLOAD, verifier.meta['reference']),
             'checked': verifier.checked, 'failed': verifier.failed}
+    if world > 1 and strong and not args.no_extras:
+        watchdog.cancel()
 
     if rank == 0:
-        cnt = b - a
-        free_bytes = 8.0*((col.num_states +
-                           col.num_unknown_input_trajectories)*(cnt + 1))
-        # algorithmic bytes of one launch: read the free
-        # columns of the launch's nodes once, write the outputs once
-        jac_bytes = free_bytes + 8.0*P*cnt
-        con_bytes = free_bytes + 8.0*M*cnt
-        if args.serial:
-            dom, dom_ms, dom_bytes = 'opty_jac', jac_ms, jac_bytes
-        else:
-            dom, dom_ms = 'opty_conjac', fused_ms
-            dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
-        achieved = dom_bytes/(dom_ms*1e-3)/1e9
-        kmeta = col._kernel_meta['kernels'][
-            'jac' if args.serial else 'conjac']
-        traffic = lookup_traffic(kmeta['sha']) \
-            if (world == 1 and args.nodes == 100000) else None
-        value = args.steps*(1 if strong else world)/elapsed
-        nnz_total = P*(N - 1)*(1 if strong else world)
-        out = {
-            'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
-                      '(10-link pendulum on cart, backward Euler)',
-            'value': value, 'unit': 'evals/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3*elapsed/args.steps,
-            'higher_is_better': True,
-            'scaling': 'strong' if strong else 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {
-                'workload': (
-                    '10-link inverted pendulum on cart, %d nodes%s, backward '
-                    'Euler, n=M=22, q=1, C=45, nnz=%d' % (
-                        N, ' per GPU' if not strong else
-                        (' sharded over %d GPUs (BASELINE config 4)' % world
-                         if world > 1 else ''), nnz_total)),
-                'step': ('constraints then Jacobian, two launches'
-                         if args.serial else
-                         'constraints and Jacobian of one free vector from '
-                         'one launch (opty_hip_eval_shard / '
-                         'opty_hip_eval_con_jac)'),
-                'sharding': (
-                    'ONE problem, constraint nodes [%d, %d) of %d on rank 0 '
-                    '(contiguous ranges, one-node halo); outputs left '
-                    'distributed, no data-path collective' % (a, b, N - 1)
-                    if strong else
-                    'independent %d-node problems, one per GPU' % N),
-                'oversubscribed': bool(oversub),
-                'prewarm_ms': args.prewarm_ms,
-                'code_object_sha': col._kernel_meta['sha'][:16],
-                'kernel_sha': kmeta['sha'][:16],
-                'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
-                hip.desc['jac_waves_per_wg'],
-                'GBps_nnz_written': 8.0*P*cnt/(jac_ms*1e-3)/1e9,
-                'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
-                              'opty_conjac': fused_ms},
-                'nodes_per_launch': cnt,
-            },
-            'roofline': {
-                'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
-                'algorithmic_bytes_per_launch': dom_bytes,
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic},
-        }
-        out['config'].update(extras)
-        out['config']['verify'] = verify
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(args.nodes)
-        print(json.dumps(out))
+        print(json.dumps(headline(extras, verify)))
     if world > 1:
         dist.destroy_process_group()
     if verify['ok'] is False:

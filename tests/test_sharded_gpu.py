@@ -347,6 +347,31 @@ def test_bench_strong_scaling_oversubscribed(world):
         assert tag in labels, ver
 
 
+def test_bench_watchdog_prints_the_headline():
+    """The re-assembly variants are the only part of ``bench.py`` that
+    exchanges data between ranks; if they hang (here: a limit they cannot
+    meet) the measured and verified headline line still appears, from rank
+    0, and every rank ends with status 0."""
+    env = dict(os.environ, OPTY_BENCH_OVERSUBSCRIBE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0',
+               OPTY_BENCH_VARIANTS_TIMEOUT='0.2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'),
+           '--gpus', '2', '--steps', '5', '--warmup', '2', '--prewarm-ms',
+           '20', '--no-cpu-baseline']
+    proc = subprocess.run(cmd, capture_output=True, text=True, cwd=REPO,
+                          env=env, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['value'] > 0
+    assert 'watchdog' in res['config']['variants_error']
+    assert res['config']['verify']['ok'] is True
+    assert 'benched launch' in ' '.join(res['config']['verify']['checked'])
+
+
 def test_bench_single_gpu_line_verifies_itself():
     """``bench.py`` as the driver runs it at N = 1: the JSON line carries
     ``config.verify.ok`` from checking the timed launch against the
