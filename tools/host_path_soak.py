@@ -59,7 +59,34 @@ for name in ('config3_10link_small', 'gaitlike_3link_be_small',
                       np.abs(c - want_c).max(), 'jac', dj_.max(),
                       'at entries', sorted(set(np.nonzero(dj_)[0][:50] % P)),
                       flush=True)
+        # the same triplets in the varying-first order (opt-in layout): as a
+        # permutation of the default layout's vector
+        vf = opty_amd.ConstraintCollocator(
+            jacobian_layout='varying_first',
+            **factory(**dict(fkw, num_nodes=nodes)))
+        order, seg_len, source = vf.jacobian_segments()
+        vjf = vf.generate_jacobian_function()
+        for seed in (1, 2):
+            free = problems.make_free(col.num_free, seed=seed,
+                                      variable_duration=col._variable_duration)
+            got = np.array(vjf(free))
+            want = np.array(jf(free))
+            blk = want[:P*ncn].reshape(ncn, P)
+            re = np.empty_like(blk)
+            at = 0
+            for L in (int(x) for x in seg_len):
+                re[:, order[at:at + L]] = got[at*ncn:(at + L)*ncn].reshape(
+                    ncn, L)
+                at += L
+            total += 1
+            scale = max(1.0, float(np.abs(want).max()))
+            if not (np.abs(re - blk).max() <= 1e-11*scale and
+                    np.array_equal(got[P*ncn:], want[P*ncn:])):
+                bad += 1
+                print('MISMATCH varying_first', name, nodes, seed,
+                      np.abs(re - blk).max(), flush=True)
+        vf.hip.close()
         hip.close()
-        del cf, jf, col
+        del cf, jf, col, vjf, vf
 print('host path soak: %d evaluations, %d mismatches' % (total, bad))
 sys.exit(1 if bad else 0)
