@@ -201,7 +201,26 @@ public:
         double *seg_dst = nullptr;
         const int *seg_pos = nullptr;
         int L0 = 0, L1 = 0;
+        // staging: chunk c copies the columns [bounds[c], bounds[c + 1]) of
+        // a (rows x pitch) matrix from rows_src to rows_dst (same layout) --
+        // the caller's pageable vectors into / out of page-locked memory, in
+        // the windows the device pipeline consumes / produces them
+        const double *rows_src = nullptr;
+        double *rows_dst = nullptr;
+        const long long *bounds = nullptr;
+        long long rows = 0, pitch = 0;
     };
+
+    // chunk c of the running job has been finished by every worker
+    bool chunk_finished(int c) const {
+        return chunk_done_[c].load(std::memory_order_acquire) >= threads();
+    }
+    void wait_chunk(int c) const {
+        for (unsigned spins = 0; !chunk_finished(c); ++spins) {
+            if (spins < 4096) cpu_relax();
+            else std::this_thread::yield();
+        }
+    }
 
     static ScatterPool &instance() {
         static ScatterPool *pool = nullptr;
@@ -315,6 +334,8 @@ public:
         job_ = job;
         ready_.store(0, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
+        for (int c = 0; c < std::min(job.chunks, MAX_CHUNKS); ++c)
+            chunk_done_[c].store(0, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(m_);
             ++epoch_;
@@ -406,6 +427,20 @@ private:
                                 b = j.nodes*(c + 1)/j.chunks;
                 const long long i0 = a + (b - a)*t/T,
                                 i1 = a + (b - a)*(t + 1)/T;
+                if (j.rows_dst) {
+                    const long long c0 = j.bounds[c], c1 = j.bounds[c + 1];
+                    const long long s0 = c0 + (c1 - c0)*t/T,
+                                    s1 = c0 + (c1 - c0)*(t + 1)/T;
+                    if (s1 > s0)
+                        for (long long r = 0; r < j.rows; ++r)
+                            memcpy(j.rows_dst + r*j.pitch + s0,
+                                   j.rows_src + r*j.pitch + s0,
+                                   (size_t)(s1 - s0)*sizeof(double));
+                    if (c < MAX_CHUNKS)
+                        chunk_done_[c].fetch_add(1,
+                                                 std::memory_order_release);
+                    continue;
+                }
                 if (j.seg_dst) {
                     for (long long i = i0; i < i1; ++i) {
                         const double *src = j.seg_src + i*j.L0;
@@ -456,6 +491,10 @@ private:
     bool quit_ = false;
     Job job_;
     std::atomic<int> ready_{0}, done_{0};
+public:
+    static constexpr int MAX_CHUNKS = 64;
+private:
+    std::atomic<int> chunk_done_[MAX_CHUNKS];
 };
 
 }  // namespace
@@ -722,6 +761,82 @@ double *mapped_address(double *host) {
     return static_cast<double *>(attr.devicePointer);
 }
 
+// Upload of the trajectory rows of a HOST `free` vector in node windows
+// (window w of W covers the constraint nodes [ncn*w/W, ncn*(w+1)/W) and needs
+// the time nodes up to its last node + 1): 2-D copies of the rows' columns,
+// from the caller's vector when it is page-locked, else from a page-locked
+// staging vector that the host threads fill window by window (a pageable
+// vector would make every 2-D copy a blocking, slow staging inside the
+// runtime).  With W == 1 one plain copy.  The parameters / node time interval
+// at the end of `free` go first.
+int host_numa_node_of(const void *addr);
+
+class FreeUploader {
+public:
+    int begin(opty_hip_problem *p, const double *free_, int W) {
+        p_ = p;
+        W_ = W;
+        N_ = p->d.N;
+        rows_ = (long long)p->d.n + p->d.q;
+        const long long rest = p->num_free() - rows_*N_;
+        src_ = free_;
+        if (W <= 1) {
+            HIP_TRY(hipMemcpyAsync(p->d_free, free_,
+                                   (size_t)p->num_free()*sizeof(double),
+                                   hipMemcpyHostToDevice, p->stream));
+            return 0;
+        }
+        if (rest > 0)
+            HIP_TRY(hipMemcpyAsync(p->d_free + rows_*N_, free_ + rows_*N_,
+                                   (size_t)rest*sizeof(double),
+                                   hipMemcpyHostToDevice, p->stream));
+        if (mapped_address(const_cast<double *>(free_)) != nullptr) return 0;
+        if (int rc = ensure_pinned(&p->h_free, (size_t)p->num_free()))
+            return rc;
+        const long long ncn = p->ncon_nodes();
+        bounds_.assign((size_t)W + 1, 0);
+        for (int w = 0; w < W; ++w) bounds_[(size_t)w + 1] = ncn*(w + 1)/W + 1;
+        pool_ = &ScatterPool::instance();
+        pool_->set_numa_node(host_numa_node_of(p->h_free));
+        ScatterPool::Job job;
+        job.rows_src = free_;
+        job.rows_dst = p->h_free;
+        job.bounds = bounds_.data();
+        job.rows = rows_;
+        job.pitch = N_;
+        job.chunks = W;
+        pool_->start(job);
+        pool_->ready(W);
+        src_ = p->h_free;
+        return 0;
+    }
+    // columns [c0, c1) of every row, for window w
+    int window(int w, long long c0, long long c1) {
+        if (W_ <= 1 || c1 <= c0) return 0;
+        if (pool_) pool_->wait_chunk(w);
+        HIP_TRY(hipMemcpy2DAsync(p_->d_free + c0, (size_t)N_*sizeof(double),
+                                 src_ + c0, (size_t)N_*sizeof(double),
+                                 (size_t)(c1 - c0)*sizeof(double),
+                                 (size_t)rows_, hipMemcpyHostToDevice,
+                                 p_->stream));
+        return 0;
+    }
+    // the staging job holds the pool: release it before another job starts
+    void end() {
+        if (pool_) pool_->wait();
+        pool_ = nullptr;
+    }
+    ~FreeUploader() { end(); }
+
+private:
+    opty_hip_problem *p_ = nullptr;
+    ScatterPool *pool_ = nullptr;
+    const double *src_ = nullptr;
+    std::vector<long long> bounds_;
+    long long N_ = 0, rows_ = 0;
+    int W_ = 1;
+};
+
 int eval_mapped(opty_hip_problem *p, int what, const double *free_,
                 double *con, double *jac) {
     const bool want_con = what != OPTY_HIP_EVAL_JAC;
@@ -774,6 +889,9 @@ int eval_mapped(opty_hip_problem *p, int what, const double *free_,
 
 int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                    double *con, double *jac, int mem, bool full);
+int eval_con_windows(opty_hip_problem *p, const double *free_, double *con,
+                     int W);
+int host_windows_of(const opty_hip_problem *p, size_t bytes, long long count);
 
 int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
              double *jac, int mem) {
@@ -802,6 +920,10 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
         (want_jac ? p->nnz() : 0));
     if (moved <= OPTY_LATENCY_PATH_BYTES && !getenv("OPTY_HIP_NO_LATENCY_PATH"))
         return eval_mapped(p, what, free_, con, jac);
+    if (what == OPTY_HIP_EVAL_CON) {
+        const int W = host_windows_of(p, moved, p->ncon_nodes());
+        if (W > 1) return eval_con_windows(p, free_, con, W);
+    }
     // Host buffers (the cyipopt callback case): stage through device memory.
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
     if (want_con)
@@ -1700,6 +1822,12 @@ static int host_numa_node(const void *addr) {
 // threads while the next chunk is in flight.  Synchronous.
 static bool packing_pays(const opty_hip_problem *p);
 
+}  // extern "C"
+namespace {
+int host_numa_node_of(const void *addr) { return host_numa_node(addr); }
+}  // namespace
+extern "C" {
+
 //
 // `produce(a, b)`, when given with !full, enqueues the evaluation of the nodes
 // [a, b) of d_blocks on the handle's stream: the nodes are then evaluated and
@@ -1708,9 +1836,24 @@ static bool packing_pays(const opty_hip_problem *p);
 // 10-link pendulum at N = 10^5, is no longer serial).
 typedef std::function<int(long long, long long)> Producer;
 
+// node windows of a host pipeline that moves `bytes` per call over `count`
+// nodes (OPTY_HIP_HOST_WINDOWS overrides); never on the legacy stream: an
+// event recorded there and waited for on another stream crashed inside the
+// runtime (ROCm 7.0.2)
+static int host_windows(const opty_hip_problem *p, size_t bytes,
+                        long long count) {
+    if (p->stream == (hipStream_t)OPTY_HIP_STREAM_LEGACY || bytes == 0)
+        return 1;
+    const char *env_w = getenv("OPTY_HIP_HOST_WINDOWS");
+    int W = env_w ? std::max(1, std::min(64, atoi(env_w)))
+                  : (bytes >= (32u << 20) ? 8 : 1);
+    return (int)std::min<long long>(W, std::max<long long>(1, count/64));
+}
+
 static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                                double *h_blocks, long long count, bool full,
-                               const Producer &produce = Producer()) {
+                               const Producer &produce = Producer(),
+                               int windows = 0) {
     const int V = (int)p->var_entries.size();
     const long long P = p->P();
     if (count <= 0) return 0;
@@ -1763,11 +1906,9 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     // recorded there and waited for on another stream crashed inside the
     // runtime (ROCm 7.0.2)
     int W = 1;
-    if (produce && p->stream != (hipStream_t)OPTY_HIP_STREAM_LEGACY &&
-        packed*sizeof(double) >= (32u << 20)) {
-        const char *env_w = getenv("OPTY_HIP_HOST_WINDOWS");
-        W = env_w ? std::max(1, std::min(64, atoi(env_w))) : 8;
-        W = (int)std::min<long long>(W, std::max<long long>(1, count/64));
+    if (produce) {
+        W = windows > 0 ? windows
+                        : host_windows(p, packed*sizeof(double), count);
         chunks = std::max(chunks, W);
     }
     while ((int)p->chunk_events.size() < chunks + W) {
@@ -1896,34 +2037,44 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
     if (int rc = ensure(&p->d_jac, (size_t)p->nnz())) return rc;
     if (int rc = order_streams(p)) return rc;
-    HIP_TRY(hipMemcpyAsync(p->d_free, free_, p->num_free()*sizeof(double),
-                           hipMemcpyHostToDevice, p->stream));
     // `fresh`: the caller's word that `jac` does not hold this handle's
     // invariant entries.  The address alone proves nothing -- a freed block
     // can come back from the allocator at the same address.
     const bool full = fresh != 0 || !p->static_valid ||
                       p->static_host != jac || !packing_pays(p);
     Producer produce;
+    FreeUploader up;
+    int W = 1, w = 0;
     if (full) {
+        if (int rc = up.begin(p, free_, 1)) return rc;
         if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
                                  p->d_jac, whole(p), true))
             return rc;
     } else {
-        // evaluated window by window inside move_blocks_to_host; the
-        // instance tails (they read all of `free` and the node-invariant
-        // table the first window fills) behind the last window
-        produce = [p, P, ncn](long long a, long long b) {
+        // uploaded, evaluated and packed window by window inside
+        // move_blocks_to_host; the instance tails (they read all of `free`
+        // and the node-invariant table the first window fills) behind the
+        // last window
+        W = host_windows(p, p->var_entries.size()*(size_t)ncn*sizeof(double),
+                         ncn);
+        if (int rc = up.begin(p, free_, W)) return rc;
+        produce = [p, P, ncn, &up, &w](long long a, long long b) {
+            if (int rc = up.window(w++, a == 0 ? a : a + 1, b + 1)) return rc;
             if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
                                      p->d_jac + a*P, NodeRange{a, b, ncn},
                                      false))
                 return rc;
-            if (b == ncn && p->d.num_inst > 0)
-                return launch_instance(p, p->d_free, nullptr,
-                                       p->d_jac + P*ncn);
+            if (b == ncn) {
+                up.end();       // the scatter job needs the host threads
+                if (p->d.num_inst > 0)
+                    return launch_instance(p, p->d_free, nullptr,
+                                           p->d_jac + P*ncn);
+            }
             return 0;
         };
     }
-    if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full, produce)) {
+    if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full, produce,
+                                     W)) {
         p->static_valid = false;
         return rc;
     }
@@ -2028,6 +2179,95 @@ int opty_hip_set_segments(opty_hip_problem *p, const int32_t *order,
 
 namespace {
 
+int host_windows_of(const opty_hip_problem *p, size_t bytes, long long count) {
+    return host_windows(p, bytes, count);
+}
+
+// constraints(free) of a large problem with HOST buffers: 18 MB up, 18 MB
+// down for the 10-link pendulum at N = 10^5 -- serial they cost 0.69 ms, and
+// PCIe is full duplex.  Node windows: window w + 1 is uploaded and evaluated
+// while the constraint rows of window w come down on a stream of their own
+// (2-D copies: M row segments of the equation-major vector); pageable caller
+// memory goes through page-locked staging vectors that the host threads
+// fill / drain window by window.
+int eval_con_windows(opty_hip_problem *p, const double *free_, double *con,
+                     int W) {
+    const long long ncn = p->ncon_nodes(), M = p->d.M;
+    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
+    if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
+    if (int rc = order_streams(p)) return rc;
+    if (!p->copy_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
+                                         hipStreamNonBlocking));
+    const bool pinned_out = mapped_address(con) != nullptr;
+    double *stage = con;
+    if (!pinned_out) {
+        if (int rc = ensure_pinned(&p->h_con, (size_t)p->num_con()))
+            return rc;
+        stage = p->h_con;
+    }
+    while ((int)p->chunk_events.size() < 2*W) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->chunk_events.push_back(e);
+    }
+    FreeUploader up;
+    if (int rc = up.begin(p, free_, W)) return rc;
+    std::vector<long long> bounds((size_t)W + 1, 0);
+    for (int w = 0; w < W; ++w) {
+        const long long a = ncn*w/W, b = ncn*(w + 1)/W;
+        bounds[(size_t)w + 1] = b;
+        if (int rc = up.window(w, w == 0 ? a : a + 1, b + 1)) return rc;
+        if (int rc = eval_device(p, OPTY_HIP_EVAL_CON, p->d_free,
+                                 p->d_con + a, nullptr, NodeRange{a, b, ncn},
+                                 false))
+            return rc;
+        HIP_TRY(hipEventRecord(p->chunk_events[(size_t)W + (size_t)w],
+                               p->stream));
+        HIP_TRY(hipStreamWaitEvent(p->copy_stream,
+                                   p->chunk_events[(size_t)W + (size_t)w],
+                                   0));
+        HIP_TRY(hipMemcpy2DAsync(stage + a, (size_t)ncn*sizeof(double),
+                                 p->d_con + a, (size_t)ncn*sizeof(double),
+                                 (size_t)(b - a)*sizeof(double), (size_t)M,
+                                 hipMemcpyDeviceToHost, p->copy_stream));
+        HIP_TRY(hipEventRecord(p->chunk_events[(size_t)w], p->copy_stream));
+    }
+    up.end();
+    if (p->d.num_inst > 0) {
+        if (int rc = launch_instance(p, p->d_free, p->d_con + M*ncn, nullptr))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(con + M*ncn, p->d_con + M*ncn,
+                               (size_t)p->d.num_inst*sizeof(double),
+                               hipMemcpyDeviceToHost, p->stream));
+    }
+    int rc = 0;
+    ScatterPool *pool = nullptr;
+    if (!pinned_out) {
+        pool = &ScatterPool::instance();
+        pool->set_numa_node(host_numa_node_of(stage));
+        ScatterPool::Job job;
+        job.rows_src = stage;
+        job.rows_dst = con;
+        job.bounds = bounds.data();
+        job.rows = M;
+        job.pitch = ncn;
+        job.chunks = W;
+        pool->start(job);
+    }
+    for (int w = 0; w < W; ++w) {
+        const hipError_t e = hipEventSynchronize(p->chunk_events[(size_t)w]);
+        if (e != hipSuccess && rc == 0)
+            rc = fail("hipEventSynchronize: %s", hipGetErrorString(e));
+        if (pool) pool->ready(w + 1);
+    }
+    if (pool) pool->wait();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    HIP_TRY(hipStreamSynchronize(p->copy_stream));
+    return 0;
+}
+
 // gathers segment `sgm` of every node's block from the node-major vector
 int pack_segment(opty_hip_problem *p, const double *dense, double *out,
                  int sgm, long long count) {
@@ -2093,20 +2333,12 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
     // whole problem's (0.5 of 4.8 ms for the 10-link pendulum at N = 10^5).
     // (An event recorded on hipStreamLegacy and waited for on another stream
     // crashed inside the runtime, ROCm 7.0.2: one window there.)
-    const char *env_w = getenv("OPTY_HIP_HOST_WINDOWS");
-    const int want_windows = env_w ? std::max(1, std::min(64, atoi(env_w)))
-                                   : 0;
     const size_t head_bytes = (size_t)L0*ncn*sizeof(double);
-    int W = want_windows ? want_windows
-                         : (head_bytes >= (32u << 20) ? 8 : 1);
-    if (p->stream == (hipStream_t)OPTY_HIP_STREAM_LEGACY) W = 1;
-    W = (int)std::min<long long>(W, std::max<long long>(1, ncn/64));
+    const int W = host_windows(p, head_bytes, ncn);
     if (W > 1 && !p->copy_stream)
         HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
                                          hipStreamNonBlocking));
     hipStream_t out = W > 1 ? p->copy_stream : p->stream;
-    const long long rows = (long long)p->d.n + p->d.q;
-    const long long rest = p->num_free() - rows*N;      // parameters, h
     // DMA chunks of about 16 MB: long enough for the engine's full rate,
     // short enough that the host threads start early and finish soon after
     // the last byte has landed
@@ -2122,32 +2354,14 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         p->chunk_events.push_back(e);
     }
-    // A page-locked `free` is uploaded window by window (2-D copies of the
-    // trajectory rows); a pageable one -- what a NumPy caller hands over --
-    // in one piece: the runtime stages pageable memory itself, at 55 GB/s
-    // for one long copy and much less for strided ones.
-    const bool by_window = W > 1 &&
-        mapped_address(const_cast<double *>(free_)) != nullptr;
-    if (!by_window)
-        HIP_TRY(hipMemcpyAsync(p->d_free, free_,
-                               (size_t)p->num_free()*sizeof(double),
-                               hipMemcpyHostToDevice, p->stream));
-    else if (rest > 0)
-        HIP_TRY(hipMemcpyAsync(p->d_free + rows*N, free_ + rows*N,
-                               (size_t)rest*sizeof(double),
-                               hipMemcpyHostToDevice, p->stream));
+    FreeUploader up;
+    if (int rc = up.begin(p, free_, W)) return rc;
     int next_chunk = 0;
     for (int w = 0; w < W; ++w) {
         const long long a = ncn*w/W, b = ncn*(w + 1)/W;
         // time nodes [a, b] of every trajectory row (one-node halo; the
         // first column of a later window is there already)
-        const long long c0 = w == 0 ? a : a + 1;
-        if (by_window)
-            HIP_TRY(hipMemcpy2DAsync(p->d_free + c0, (size_t)N*sizeof(double),
-                                     free_ + c0, (size_t)N*sizeof(double),
-                                     (size_t)(b + 1 - c0)*sizeof(double),
-                                     (size_t)rows, hipMemcpyHostToDevice,
-                                     p->stream));
+        if (int rc = up.window(w, w == 0 ? a : a + 1, b + 1)) return rc;
         const NodeRange rg{a, b, ncn};
         if (int rc = eval_device(p, what, p->d_free, dcon ? dcon + a : nullptr,
                                  p->d_dense + a*P, rg, false))
@@ -2179,6 +2393,7 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
             ++next_chunk;
         }
     }
+    up.end();
     // instance tails (they read the whole free vector), constraints, and --
     // `full` -- the node-invariant segment, behind the entries that vary
     if (p->d.num_inst > 0)

@@ -807,6 +807,53 @@ def test_persistent_jacobian_moves_only_what_changed(name, N):
     assert hb.host_threads() >= 1
 
 
+@pytest.mark.parametrize('windows', [None, '1', '3', '7'])
+@pytest.mark.parametrize('name,N', [('config3_10link', 20001),
+                                    ('config2_pendulum', 200001),
+                                    ('pend2_link_vardur_unkmass_small', 60001),
+                                    ('gaitlike_3link_be_small', 30001)])
+def test_host_pipelines_in_node_windows(name, N, windows, monkeypatch):
+    """``constraints(free)`` and ``jacobian(free)`` of problems too large for
+    the latency path run as pipelines over node windows (upload -- from the
+    caller's vector when it is page-locked, else through a staging vector the
+    host threads fill --, evaluation, download on a stream of its own).
+    Forced window counts (ragged windows, one window), page-locked and
+    pageable vectors, instance tails, a free node time interval and unknown
+    parameters behind the trajectory rows: all equal to the device-pointer
+    evaluation of the same handle."""
+    import torch
+    from opty_amd import hip_backend as hb
+    if windows:
+        monkeypatch.setenv('OPTY_HIP_HOST_WINDOWS', windows)
+    col = _collocator(name, num_nodes=N)
+    hip = col.hip
+    vd = col._variable_duration
+    cf, jf = (col.generate_constraint_function(),
+              col.generate_jacobian_function())
+    for seed in (1, 2, 3):
+        free = problems.make_free(col.num_free, seed=seed,
+                                  variable_duration=vd)
+        d_free = torch.from_numpy(free).cuda()
+        dc = torch.empty(col.num_constraints, dtype=torch.float64,
+                         device='cuda')
+        dj = torch.empty(hip.nnz, dtype=torch.float64, device='cuda')
+        hip.eval_con(d_free, dc, hb.DEVICE)
+        hip.eval_jac(d_free, dj, hb.DEVICE)
+        hip.synchronize()
+        want_c, want_j = dc.cpu().numpy(), dj.cpu().numpy()
+        pinned = hb.pinned_empty(len(free))
+        pinned[:] = free
+        for vec in (free, pinned):
+            got = cf(vec)
+            np.testing.assert_array_equal(got, want_c)
+            out = hb.pinned_empty(col.num_constraints)
+            hip.eval_con(vec, out, hb.HOST)          # page-locked result
+            np.testing.assert_array_equal(out, want_c)
+            j = jf(vec)
+            np.testing.assert_allclose(j, want_j, rtol=1e-10,
+                                       atol=1e-12*np.abs(want_j).max())
+
+
 def test_persistent_jacobian_does_not_trust_a_reused_address():
     """A host vector at the address of an earlier one is NOT taken to hold
     the invariant entries: the closure of ``generate_jacobian_function`` says
