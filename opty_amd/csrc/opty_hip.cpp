@@ -769,8 +769,6 @@ double *mapped_address(double *host) {
 // vector would make every 2-D copy a blocking, slow staging inside the
 // runtime).  With W == 1 one plain copy.  The parameters / node time interval
 // at the end of `free` go first.
-int host_numa_node_of(const void *addr);
-
 class FreeUploader {
 public:
     int begin(opty_hip_problem *p, const double *free_, int W) {
@@ -796,8 +794,9 @@ public:
         const long long ncn = p->ncon_nodes();
         bounds_.assign((size_t)W + 1, 0);
         for (int w = 0; w < W; ++w) bounds_[(size_t)w + 1] = ncn*(w + 1)/W + 1;
+        // (the workers stay where the last scatter put them: restarting
+        // them on another NUMA node costs more than a remote memcpy)
         pool_ = &ScatterPool::instance();
-        pool_->set_numa_node(host_numa_node_of(p->h_free));
         ScatterPool::Job job;
         job.rows_src = free_;
         job.rows_dst = p->h_free;
@@ -889,9 +888,6 @@ int eval_mapped(opty_hip_problem *p, int what, const double *free_,
 
 int eval_segmented(opty_hip_problem *p, int what, const double *free_,
                    double *con, double *jac, int mem, bool full);
-int eval_con_windows(opty_hip_problem *p, const double *free_, double *con,
-                     int W);
-int host_windows_of(const opty_hip_problem *p, size_t bytes, long long count);
 
 int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
              double *jac, int mem) {
@@ -920,10 +916,6 @@ int eval_any(opty_hip_problem *p, int what, const double *free_, double *con,
         (want_jac ? p->nnz() : 0));
     if (moved <= OPTY_LATENCY_PATH_BYTES && !getenv("OPTY_HIP_NO_LATENCY_PATH"))
         return eval_mapped(p, what, free_, con, jac);
-    if (what == OPTY_HIP_EVAL_CON) {
-        const int W = host_windows_of(p, moved, p->ncon_nodes());
-        if (W > 1) return eval_con_windows(p, free_, con, W);
-    }
     // Host buffers (the cyipopt callback case): stage through device memory.
     if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
     if (want_con)
@@ -1822,12 +1814,6 @@ static int host_numa_node(const void *addr) {
 // threads while the next chunk is in flight.  Synchronous.
 static bool packing_pays(const opty_hip_problem *p);
 
-}  // extern "C"
-namespace {
-int host_numa_node_of(const void *addr) { return host_numa_node(addr); }
-}  // namespace
-extern "C" {
-
 //
 // `produce(a, b)`, when given with !full, enqueues the evaluation of the nodes
 // [a, b) of d_blocks on the handle's stream: the nodes are then evaluated and
@@ -2178,95 +2164,6 @@ int opty_hip_set_segments(opty_hip_problem *p, const int32_t *order,
 }  // extern "C"
 
 namespace {
-
-int host_windows_of(const opty_hip_problem *p, size_t bytes, long long count) {
-    return host_windows(p, bytes, count);
-}
-
-// constraints(free) of a large problem with HOST buffers: 18 MB up, 18 MB
-// down for the 10-link pendulum at N = 10^5 -- serial they cost 0.69 ms, and
-// PCIe is full duplex.  Node windows: window w + 1 is uploaded and evaluated
-// while the constraint rows of window w come down on a stream of their own
-// (2-D copies: M row segments of the equation-major vector); pageable caller
-// memory goes through page-locked staging vectors that the host threads
-// fill / drain window by window.
-int eval_con_windows(opty_hip_problem *p, const double *free_, double *con,
-                     int W) {
-    const long long ncn = p->ncon_nodes(), M = p->d.M;
-    if (int rc = ensure(&p->d_free, (size_t)p->num_free())) return rc;
-    if (int rc = ensure(&p->d_con, (size_t)p->num_con())) return rc;
-    if (int rc = order_streams(p)) return rc;
-    if (!p->copy_stream)
-        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
-                                         hipStreamNonBlocking));
-    const bool pinned_out = mapped_address(con) != nullptr;
-    double *stage = con;
-    if (!pinned_out) {
-        if (int rc = ensure_pinned(&p->h_con, (size_t)p->num_con()))
-            return rc;
-        stage = p->h_con;
-    }
-    while ((int)p->chunk_events.size() < 2*W) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        p->chunk_events.push_back(e);
-    }
-    FreeUploader up;
-    if (int rc = up.begin(p, free_, W)) return rc;
-    std::vector<long long> bounds((size_t)W + 1, 0);
-    for (int w = 0; w < W; ++w) {
-        const long long a = ncn*w/W, b = ncn*(w + 1)/W;
-        bounds[(size_t)w + 1] = b;
-        if (int rc = up.window(w, w == 0 ? a : a + 1, b + 1)) return rc;
-        if (int rc = eval_device(p, OPTY_HIP_EVAL_CON, p->d_free,
-                                 p->d_con + a, nullptr, NodeRange{a, b, ncn},
-                                 false))
-            return rc;
-        HIP_TRY(hipEventRecord(p->chunk_events[(size_t)W + (size_t)w],
-                               p->stream));
-        HIP_TRY(hipStreamWaitEvent(p->copy_stream,
-                                   p->chunk_events[(size_t)W + (size_t)w],
-                                   0));
-        HIP_TRY(hipMemcpy2DAsync(stage + a, (size_t)ncn*sizeof(double),
-                                 p->d_con + a, (size_t)ncn*sizeof(double),
-                                 (size_t)(b - a)*sizeof(double), (size_t)M,
-                                 hipMemcpyDeviceToHost, p->copy_stream));
-        HIP_TRY(hipEventRecord(p->chunk_events[(size_t)w], p->copy_stream));
-    }
-    up.end();
-    if (p->d.num_inst > 0) {
-        if (int rc = launch_instance(p, p->d_free, p->d_con + M*ncn, nullptr))
-            return rc;
-        HIP_TRY(hipMemcpyAsync(con + M*ncn, p->d_con + M*ncn,
-                               (size_t)p->d.num_inst*sizeof(double),
-                               hipMemcpyDeviceToHost, p->stream));
-    }
-    int rc = 0;
-    ScatterPool *pool = nullptr;
-    if (!pinned_out) {
-        pool = &ScatterPool::instance();
-        pool->set_numa_node(host_numa_node_of(stage));
-        ScatterPool::Job job;
-        job.rows_src = stage;
-        job.rows_dst = con;
-        job.bounds = bounds.data();
-        job.rows = M;
-        job.pitch = ncn;
-        job.chunks = W;
-        pool->start(job);
-    }
-    for (int w = 0; w < W; ++w) {
-        const hipError_t e = hipEventSynchronize(p->chunk_events[(size_t)w]);
-        if (e != hipSuccess && rc == 0)
-            rc = fail("hipEventSynchronize: %s", hipGetErrorString(e));
-        if (pool) pool->ready(w + 1);
-    }
-    if (pool) pool->wait();
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
-    HIP_TRY(hipStreamSynchronize(p->copy_stream));
-    return 0;
-}
 
 // gathers segment `sgm` of every node's block from the node-major vector
 int pack_segment(opty_hip_problem *p, const double *dense, double *out,

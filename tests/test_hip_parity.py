@@ -813,10 +813,10 @@ def test_persistent_jacobian_moves_only_what_changed(name, N):
                                     ('pend2_link_vardur_unkmass_small', 60001),
                                     ('gaitlike_3link_be_small', 30001)])
 def test_host_pipelines_in_node_windows(name, N, windows, monkeypatch):
-    """``constraints(free)`` and ``jacobian(free)`` of problems too large for
-    the latency path run as pipelines over node windows (upload -- from the
-    caller's vector when it is page-locked, else through a staging vector the
-    host threads fill --, evaluation, download on a stream of its own).
+    """``jacobian(free)`` of problems too large for the latency path runs as
+    a pipeline over node windows (upload -- from the caller's vector when it
+    is page-locked, else through a staging vector the host threads fill --,
+    evaluation, packing, download on a stream of its own).
     Forced window counts (ragged windows, one window), page-locked and
     pageable vectors, instance tails, a free node time interval and unknown
     parameters behind the trajectory rows: all equal to the device-pointer
