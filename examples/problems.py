@@ -21,6 +21,31 @@ __all__ = ['vyasarayani', 'pendulum_swing_up', 'n_link_cart_pendulum',
            'gait_like_pendulum', 'CONFIGS', 'make_free']
 
 
+_KANE = {}
+
+
+def _cart_pendulum(num_links):
+    """``(states, eom)`` of ``n_link_pendulum_on_cart`` (Kane's method takes
+    15 s for 24 links): derived once per process, SymPy objects are
+    immutable."""
+    if num_links not in _KANE:
+        from sympy.physics.mechanics.models import n_link_pendulum_on_cart
+        # The reference's collocator assigns ``me.dynamicsymbols._t``
+        # globally (``opty/direct_collocation.py:1492``); restore SymPy's
+        # default so the derivation always runs on the same time symbol
+        me.dynamicsymbols._t = sm.Symbol('t')
+        kane = n_link_pendulum_on_cart(n=num_links, cart_force=True,
+                                       joint_torques=False)
+        states = kane.q.col_join(kane.u)
+        t = me.dynamicsymbols._t
+        eom = sm.ImmutableDenseMatrix(
+            kane.mass_matrix_full @ states.diff(t) - kane.forcing_full)
+        _KANE[num_links] = (sm.ImmutableDenseMatrix(states), eom,
+                            tuple(kane.q), tuple(kane.u))
+    me.dynamicsymbols._t = sm.Symbol('t')
+    return _KANE[num_links]
+
+
 def vyasarayani(num_nodes=51, duration=50.0, method='backward euler'):
     """Config 1: single-pendulum parameter identification.
 
@@ -75,16 +100,8 @@ def n_link_cart_pendulum(num_links=10, num_nodes=100000, interval=0.01,
     ``variable_duration`` makes ``h`` a free Symbol (s = 1); both are used by
     parity tests to exercise every column class of the Jacobian block.
     """
-    from sympy.physics.mechanics.models import n_link_pendulum_on_cart
-    # The reference's collocator assigns ``me.dynamicsymbols._t`` globally
-    # (``opty/direct_collocation.py:1492``); restore SymPy's default so the
-    # model is built with one consistent time symbol.
-    me.dynamicsymbols._t = sm.Symbol('t')
-    kane = n_link_pendulum_on_cart(n=num_links, cart_force=True,
-                                   joint_torques=False)
-    states = kane.q.col_join(kane.u)
+    states, eom, _, _ = _cart_pendulum(num_links)
     t = me.dynamicsymbols._t
-    eom = kane.mass_matrix_full @ states.diff(t) - kane.forcing_full
     par_map = {}
     params = sorted((s for s in eom.free_symbols if s != t),
                     key=lambda s: (s.name[0], int(s.name[1:] or 0)))
@@ -378,15 +395,10 @@ def gait_like_pendulum(num_links=24, num_nodes=50000, method='backward euler',
       ``u_k(0) - u_k(T)`` and one on the unknown input, all written as integer
       multiples of ``h``.
     """
-    from sympy.physics.mechanics.models import n_link_pendulum_on_cart
-    me.dynamicsymbols._t = sm.Symbol('t')
-    kane = n_link_pendulum_on_cart(n=num_links, cart_force=True,
-                                   joint_torques=False)
-    q, u = list(kane.q), list(kane.u)
-    states = kane.q.col_join(kane.u)
+    states, eom, q, u = _cart_pendulum(num_links)
+    q, u = list(q), list(u)
     t = me.dynamicsymbols._t
-    eom = sm.Matrix(kane.mass_matrix_full @ states.diff(t) -
-                    kane.forcing_full)
+    eom = sm.Matrix(eom)
     kc, cc, kd = sm.symbols('kc, cc, kd', real=True)
     Tg = sm.Function('Tg')(t)
     nq = len(q)
