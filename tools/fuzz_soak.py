@@ -52,6 +52,20 @@ def layouts(seed, tf):
         assert np.abs(con - c_ref).max() <= 1e-10*max(
             1.0, float(np.abs(c_ref).max()))
         col.hip.close()
+    # the varying-first order (opt-in): the same triplet SET, twice (the
+    # second call moves only the varying segment)
+    col = opty_amd.ConstraintCollocator(jacobian_layout='varying_first',
+                                        **kw)
+    r, c = col.jacobian_indices()
+    o_ref, o_got = np.lexsort((cols, rows)), np.lexsort((c, r))
+    np.testing.assert_array_equal(rows[o_ref], r[o_got])
+    np.testing.assert_array_equal(cols[o_ref], c[o_got])
+    jf = col.generate_jacobian_function()
+    for _ in range(2):
+        jac = np.array(jf(free))
+        assert np.abs(jac[o_got] - j_ref[o_ref]).max() <= 1e-10*scale, \
+            (seed, 'varying_first')
+    col.hip.close()
 
 
 def sharded(seed, tf):
