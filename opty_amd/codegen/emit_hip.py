@@ -1611,5 +1611,6 @@ def emit_module(prog, opts=None, node_blocks=None):
                 geometry=seeds, layout=getattr(prog, 'layout', 'coo'),
                 num_uniform=num_uniform, uniform_dynamic=bool(dynamic),
                 inst_folded=bool(folded),
+                con_attached=bool(any(attached)),
                 sha=hashlib.sha256(source.encode()).hexdigest())
     return source, meta

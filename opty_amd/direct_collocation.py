@@ -593,10 +593,15 @@ class ConstraintCollocator(object):
             # (row-sorted blocks are cut at row starts: any count up to M)
             steps += [1, 2, 3, 4, 5, 6, 8, 10, 12]
 
-        def attempt(d):
+        def attempt(d, detach=False):
             trial = copy.copy(opts)
             if geo['con_waves'] > 1:
                 trial.con_split = 'count'
+            if detach:
+                # constraint rows back in waves of their own: the Jacobian
+                # waves they rode in (arithmetic-bound blocks, emit_hip.
+                # _attach_constraint_rows) get their registers back
+                trial.con_attach = 0
             if d:
                 trial.groups = geo['jac'] + (d if 'opty_jac' in best[2]
                                              else 0)
@@ -609,19 +614,25 @@ class ConstraintCollocator(object):
             return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta)
 
         from concurrent.futures import ThreadPoolExecutor
-        while best[2] and steps:
-            batch, steps = steps[:4], steps[4:]
-            logger.info('kernels %s spill vector registers: rebuilding with '
-                        'narrower cuts %s', sorted(best[2]), batch)
-            with ThreadPoolExecutor(len(batch)) as pool:
-                results = list(pool.map(attempt, batch))
-            clean = [r for r in results if not r[2]]
-            if clean:
-                best = clean[0]
-            else:
-                least = min(results, key=lambda r: sum(r[2].values()))
-                if sum(least[2].values()) < sum(best[2].values()):
-                    best = least
+        phases = [(False, list(steps))]
+        if meta.get('con_attached') and opts.con_attach is None:
+            phases.append((True, [0] + [d for d in steps if d]))
+        for detach, todo in phases:
+            while best[2] and todo:
+                batch, todo = todo[:4], todo[4:]
+                logger.info('kernels %s spill vector registers: rebuilding '
+                            'with narrower cuts %s%s', sorted(best[2]), batch,
+                            ', constraint rows detached' if detach else '')
+                with ThreadPoolExecutor(len(batch)) as pool:
+                    results = list(pool.map(
+                        lambda d: attempt(d, detach), batch))
+                clean = [r for r in results if not r[2]]
+                if clean:
+                    best = clean[0]
+                else:
+                    least = min(results, key=lambda r: sum(r[2].values()))
+                    if sum(least[2].values()) < sum(best[2].values()):
+                        best = least
         if best[2]:
             # No cut is spill-free (a system larger than anything in the
             # zoo).  The wrong values of round 3 followed one stage of the

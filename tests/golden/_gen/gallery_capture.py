@@ -4,6 +4,11 @@ gallery (``/root/reference/examples-gallery/*/plot_*.py``).  Build container
 only -- nothing here travels to the GPU box but the ``.npz`` data it writes.
 
     python tests/golden/_gen/gallery_capture.py [script-stem ...]
+    GALLERY_FLIP=1 python tests/golden/_gen/gallery_capture.py [...]
+
+(``GALLERY_FLIP=1``: every script once more under the OTHER discretisation
+rule -- ``gallery_<stem>__flipped.npz`` -- because 24 of the 28 use backward
+Euler.)
 
 Every script is executed (in a child process) with ``opty.Problem`` replaced
 by a subclass that (1) records the arguments the script constructs its
@@ -82,9 +87,20 @@ def _child(stem):
     # without end on a subclass of ``Problem``)
     ref_init = RefProblem.__init__
 
+    flip = os.environ.get('GALLERY_FLIP') == '1'
+
     def init(self, *args, **kwargs):
         bound = sig.bind(self, *args, **kwargs)
         bound.apply_defaults()
+        if flip:
+            # the same problem under the OTHER discretisation rule (24 of
+            # the 28 scripts use backward Euler): a second reference record
+            # per script, for the midpoint columns u_i, u_n of real problems
+            other = {'backward euler': 'midpoint',
+                     'midpoint': 'backward euler'}
+            bound.arguments['integration_method'] = other[
+                bound.arguments['integration_method']]
+            args, kwargs = bound.args[1:], bound.kwargs
         self._captured_args = dict(bound.arguments)
         t0 = time.time()
         ref_init(self, *args, **kwargs)
@@ -266,15 +282,16 @@ def _child(stem):
         break
 
     meta = dict(
-        name='gallery_' + stem[5:], script=os.path.relpath(path,
-                                                            '/root/reference'),
+        name='gallery_' + stem[5:] + ('__flipped' if flip else ''),
+        script=os.path.relpath(path, '/root/reference'),
         N=N, M=M, n=n, q=q, r=col.num_unknown_parameters, s=int(vd),
         o=col.num_instance_constraints, C=int(C),
         num_free=int(prob.num_free), num_constraints=int(col.num_constraints),
         nnz=int(len(rows)), nnz_inst=int(len(rows) - base),
         method=col.integration_method, free_recipe=recipe,
         callable_known=callable_known, layout=layout,
-        has_objective=has_objective, num_bounds=len(bound_keys),
+        has_objective=has_objective and not flip,
+        flipped=flip, num_bounds=len(bound_keys),
         num_eom_bounds=len(eom_bounds),
         states=[str(x) for x in col.state_symbols],
         known_parameters=[str(x) for x in col.known_parameters],

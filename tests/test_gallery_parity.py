@@ -1,7 +1,9 @@
 """Parity on the problems users actually run: every script of the reference's
 example gallery that builds with SymPy alone (28 of 31; the other three need
-``pygait2d`` / ``pydy`` / ``yeadon``), against goldens recorded from the REAL
-reference for the very arguments each script hands to ``Problem``
+``pygait2d`` / ``pydy`` / ``yeadon``) -- each under the discretisation rule the
+script chooses and once more under the other one (``__flipped``: 24 of the 28
+use backward Euler) --, against goldens recorded from the REAL reference for
+the very arguments each script hands to ``Problem``
 (``tests/golden/_gen/gallery_capture.py``; inputs rebuilt from data by
 :mod:`gallery_cases`).
 
@@ -25,7 +27,8 @@ RTOL = 1e-10
 #: the oracle is SymPy ``jacobian`` + ``cse`` + gcc per problem; the one
 #: fixture that takes it minutes was checked in the build container (the
 #: other 25 full fixtures take 25 s together)
-ORACLE_HEAVY = {'gallery_ball_rolling_on_spinning_disc'}
+ORACLE_HEAVY = {'gallery_ball_rolling_on_spinning_disc',
+                'gallery_ball_rolling_on_spinning_disc__flipped'}
 ORACLE_CASES = [k for k in gc.FULL if k not in ORACLE_HEAVY]
 
 
