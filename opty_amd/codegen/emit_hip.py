@@ -104,7 +104,11 @@ class EmitOptions(object):
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
-                 cut='even', con_attach=None):
+                 cut='even', con_attach=None, forget=0):
+        # 1: a strip's temporaries are dropped at every chunk boundary and
+        # recomputed where needed again (bounded register pressure; the last
+        # resort before a build that spills vector registers)
+        self.forget = int(forget)
         # fused kernel: constraint rows evaluated by the Jacobian wave that
         # already computes most of their sub-expressions instead of by a
         # constraint wave of their own (emit_module): None = automatic (blocks
@@ -225,6 +229,7 @@ class EmitOptions(object):
                 ('' if self.cut == 'even' else ' cut=work') +
                 ('' if self.con_attach is None
                  else ' con_attach=%d' % self.con_attach) +
+                (' forget=1' if self.forget else '') +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -257,6 +262,7 @@ class _Body(object):
         self.trig = 'opty_' if fast_trig else ''
         self.lines = []
         self.done = {}
+        self.gen = 0
         self.scope = {}
         self.scope_id = 0
         self.scope_start = 0
@@ -286,6 +292,16 @@ class _Body(object):
         self.scope_start = len(self.lines)
 
     begin_entry = end_scope
+
+    def forget(self):
+        """Drops every computed temporary: what is needed again is computed
+        again (under a new name).  Bounds the live values of a long strip at
+        the price of re-evaluating what its chunks share."""
+        self.done = {}
+        self.gen += 1
+
+    def _name(self, i):
+        return 'v%d' % i if self.gen == 0 else 'v%d_%d' % (i, self.gen)
 
     def ref(self, i):
         d = self.dag
@@ -340,7 +356,7 @@ class _Body(object):
         d = self.dag
         op = d.op[i]
         a = d.args[i]
-        name = 'v%d' % i
+        name = self._name(i)
         r = self.ref
         if op == ir.ADD:
             e = '%s + %s' % (r(a[0]), r(a[1]))
@@ -378,11 +394,11 @@ class _Body(object):
             if (j is not None and j in self.needed and not self._have(j)
                     and self.leaf(j) is None):
                 s_id, c_id = (i, j) if op == 'sin' else (j, i)
-                self.lines.append('double v%d, v%d; %ssincos(%s, &v%d, &v%d);'
-                                  % (s_id, c_id, self.trig, r(a[0]), s_id,
-                                     c_id))
-                self.done[s_id] = 'v%d' % s_id
-                self.done[c_id] = 'v%d' % c_id
+                sn, cn = self._name(s_id), self._name(c_id)
+                self.lines.append('double %s, %s; %ssincos(%s, &%s, &%s);'
+                                  % (sn, cn, self.trig, r(a[0]), sn, cn))
+                self.done[s_id] = sn
+                self.done[c_id] = cn
                 return
             e = '%s%s(%s)' % (self.trig, op, r(a[0]))
         elif op == 'abs':
@@ -870,6 +886,8 @@ class _ModuleWriter(object):
         for c0 in range(e0, e1 + 15, K):
             c1 = min(c0 + K, e1 + 15)
             body.new_scope()
+            if self.o.forget and c0 > e0:
+                body.forget()
             for v in range(c0, c1):
                 body.begin_entry()
                 body.lines.append('ring[%d + lane] = %s;'

@@ -593,10 +593,17 @@ class ConstraintCollocator(object):
             # (row-sorted blocks are cut at row starts: any count up to M)
             steps += [1, 2, 3, 4, 5, 6, 8, 10, 12]
 
-        def attempt(d, detach=False):
+        def attempt(d, detach=False, forget=False):
             trial = copy.copy(opts)
             if geo['con_waves'] > 1:
                 trial.con_split = 'count'
+            if forget:
+                # 16-entry chunks whose temporaries are dropped at every
+                # chunk boundary: what the chunks share is evaluated again,
+                # the live values of a wave are those of 16 entries (the
+                # midpoint rule of the muscle-driven leg: 24 spilled registers
+                # at every cut otherwise, none this way)
+                trial.forget, trial.chunk = 1, 16
             if detach:
                 # constraint rows back in waves of their own: the Jacobian
                 # waves they rode in (arithmetic-bound blocks, emit_hip.
@@ -614,18 +621,25 @@ class ConstraintCollocator(object):
             return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta)
 
         from concurrent.futures import ThreadPoolExecutor
-        phases = [(False, list(steps))]
-        if meta.get('con_attached') and opts.con_attach is None:
-            phases.append((True, [0] + [d for d in steps if d]))
-        for detach, todo in phases:
+        phases = [(False, False, list(steps))]
+        detachable = bool(meta.get('con_attached')) and \
+            opts.con_attach is None
+        if detachable:
+            phases.append((True, False, [0] + [d for d in steps if d]))
+        if geo['line_mode'] and opts.chunk == 32 and not opts.forget:
+            phases.append((detachable, True, [0, 2, 4, 8]))
+        for detach, forget, todo in phases:
             while best[2] and todo:
                 batch, todo = todo[:4], todo[4:]
                 logger.info('kernels %s spill vector registers: rebuilding '
-                            'with narrower cuts %s%s', sorted(best[2]), batch,
-                            ', constraint rows detached' if detach else '')
+                            'with narrower cuts %s%s%s', sorted(best[2]),
+                            batch,
+                            ', constraint rows detached' if detach else '',
+                            ', temporaries dropped per chunk' if forget
+                            else '')
                 with ThreadPoolExecutor(len(batch)) as pool:
                     results = list(pool.map(
-                        lambda d: attempt(d, detach), batch))
+                        lambda d: attempt(d, detach, forget), batch))
                 clean = [r for r in results if not r[2]]
                 if clean:
                     best = clean[0]
