@@ -784,6 +784,27 @@ def test_high_pressure_builds_are_marked_for_verification(name, hot):
         assert twin != hsaco and os.path.basename(twin) in before
 
 
+def test_spill_loop_falls_back_on_recomputation_per_chunk():
+    """The muscle-driven leg under the midpoint rule: every cut of its block
+    spills 24+ vector registers (with or without the constraint rows in the
+    Jacobian waves); the build loop's last phase -- 16-entry chunks whose
+    temporaries are dropped at every chunk boundary (``EmitOptions.forget``)
+    -- finds a build without vector spills, and that is the one used."""
+    import gallery_cases as gc
+    _, _, kw = gc.load('gallery_one_legged_time_trial__flipped')
+    col = ConstraintCollocator(**kw)
+    hsaco, meta = col._build_code_object()
+    assert hb.vgpr_spills(hsaco) == {}
+    assert meta['geometry']['chunk'] == 16
+    assert 'forget=1' in col._built_source.splitlines()[1]
+    # the script's own rule (backward Euler) needs no fallback
+    _, _, kw = gc.load('gallery_one_legged_time_trial')
+    col = ConstraintCollocator(**kw)
+    hsaco, meta = col._build_code_object()
+    assert hb.vgpr_spills(hsaco) == {}
+    assert 'forget=1' not in col._built_source.splitlines()[1]
+
+
 def test_kernel_metadata_guard_fails_closed(tmp_path):
     """A code object whose metadata cannot be read, or that holds none of the
     expected kernels, is an error -- not "no spills"."""
