@@ -842,3 +842,38 @@ def test_scatter_pool_honours_the_process_affinity_mask():
         pytest.skip('no taskset')
     assert run({}) == 1
     assert run({'OPTY_HIP_HOST_AFFINITY': 'wide'}) == 5
+
+
+def test_public_attributes_exist_and_are_read_only():
+    """The reference's public read-only attributes
+    (``opty/direct_collocation.py:1556-1892``; its
+    ``test_attributes_read_only`` lists them) exist under the same names and
+    cannot be assigned; ``integration_method`` alone has a setter."""
+    col = ConstraintCollocator(**problems.build('gaitlike_3link_be_small'))
+    names = '''current_discrete_state_symbols
+        current_discrete_specified_symbols
+        current_known_discrete_specified_symbols
+        current_unknown_discrete_specified_symbols discrete_eom eom
+        input_trajectories instance_constraints known_input_trajectories
+        known_parameters known_parameter_map known_trajectory_map
+        next_known_discrete_specified_symbols next_discrete_state_symbols
+        next_discrete_specified_symbols
+        next_unknown_discrete_specified_symbols node_time_interval
+        num_collocation_nodes num_constraints num_free
+        num_input_trajectories num_instance_constraints
+        num_known_input_trajectories num_known_parameters num_parameters
+        num_states num_eom num_unknown_input_trajectories
+        num_unknown_parameters parameters parallel
+        previous_discrete_state_symbols show_compile_output
+        state_derivative_symbols state_symbols time_interval_symbol
+        time_symbol tmp_dir unknown_input_trajectories
+        unknown_parameters'''.split()
+    for name in names:
+        getattr(col, name)
+        with pytest.raises(AttributeError):
+            setattr(col, name, 5)
+    col.integration_method = 'midpoint'
+    assert col.integration_method == 'midpoint'
+    assert col.num_block_columns == 2*col.num_states + \
+        2*col.num_unknown_input_trajectories + \
+        col.num_unknown_parameters + 1
