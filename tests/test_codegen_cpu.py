@@ -877,3 +877,61 @@ def test_public_attributes_exist_and_are_read_only():
     assert col.num_block_columns == 2*col.num_states + \
         2*col.num_unknown_input_trajectories + \
         col.num_unknown_parameters + 1
+
+
+def test_printer_expansions_against_sympy():
+    """Functions outside the C math table are lowered through the expansion
+    the reference's C99 printer prints for them (``lower._printer_expansion``:
+    printer hooks of ``sympy.physics.biomechanics``, ``implemented_function``,
+    the printer's rewrite table, ``UnevaluatedExpr``): values and forward-mode
+    derivatives against SymPy's own evaluation and differentiation."""
+    import sympy.physics.biomechanics as bm
+    from sympy.utilities.lambdify import implemented_function
+    a, b, c = sm.symbols('a b c', real=True)
+    xx = sm.Symbol('xx')
+    # (the printer inlines SymPy Lambdas only, not Python callables)
+    sq = implemented_function('sq', sm.Lambda(xx, xx**2 + sm.sin(xx)))
+    exprs = [
+        bm.FiberForceLengthActiveDeGroote2016.with_defaults(a)*b,
+        bm.FiberForceLengthPassiveDeGroote2016.with_defaults(a + c/4),
+        bm.FiberForceVelocityDeGroote2016.with_defaults(b - 1),
+        bm.TendonForceLengthDeGroote2016.with_defaults(1 + c/20),
+        bm.FiberForceVelocityInverseDeGroote2016.with_defaults(a),
+        bm.TendonForceLengthInverseDeGroote2016.with_defaults(b),
+        sm.acot(a*b) + sm.asec(2 + c) + sm.acsc(2 + a),
+        sq(a*c) + sm.UnevaluatedExpr(a + b)*c,
+        sm.sec(a) + sm.csc(b) + sm.cot(c) + sm.coth(a) + sm.sech(b) +
+        sm.csch(c),
+    ]
+    d = ir.DAG()
+    table = {s: d.input('cur', k) for k, s in enumerate((a, b, c))}
+    low = Lowerer(d, table)
+    outs = [low.lower(e) for e in exprs]
+    jac = forward_jacobian(d, outs, [table[s] for s in (a, b, c)])
+    rng = np.random.default_rng(3)
+    vals = rng.uniform(0.6, 1.4, size=(3, 40))
+    got = dag_interp.evaluate(d, outs, lambda kind, k: vals[k])
+    gjac = dag_interp.evaluate(d, [n for row in jac for n in row],
+                               lambda kind, k: vals[k])
+    # the same functions written out for SymPy (it cannot differentiate an
+    # implemented function or look through UnevaluatedExpr)
+    plain = list(exprs)
+    plain[7] = (a*c)**2 + sm.sin(a*c) + (a + b)*c
+    plain = [e.doit() for e in plain]
+    f = sm.lambdify((a, b, c), plain, 'numpy')
+    df = sm.lambdify((a, b, c), [sm.diff(e, s) for e in plain
+                                 for s in (a, b, c)], 'numpy')
+    ref = [np.broadcast_to(np.asarray(v, dtype=float), (40,))
+           for v in f(*vals)]
+    dref = [np.broadcast_to(np.asarray(v, dtype=float), (40,))
+            for v in df(*vals)]
+    for k in range(len(exprs)):
+        np.testing.assert_allclose(np.broadcast_to(got[k], (40,)), ref[k],
+                                   rtol=1e-12, atol=1e-13, err_msg=str(k))
+    for k in range(3*len(exprs)):
+        np.testing.assert_allclose(np.broadcast_to(gjac[k], (40,)), dref[k],
+                                   rtol=1e-11, atol=1e-12, err_msg=str(k))
+    # an undefined function has no expansion, here as in the reference
+    from opty_amd.codegen.lower import LoweringError
+    with pytest.raises(LoweringError):
+        low.lower(sm.Function('mystery')(a))
