@@ -2200,7 +2200,7 @@ int eval_segmented(opty_hip_problem *p, int what, const double *free_,
     };
     const double t_in = trace ? now() : 0.0;
     const bool want_con = what != OPTY_HIP_EVAL_JAC;
-    const long long P = p->P(), ncn = p->ncon_nodes(), N = p->d.N;
+    const long long P = p->P(), ncn = p->ncon_nodes();
     const long long L0 = p->seg_len[0], L1 = p->seg_len[1];
     const size_t tail = (size_t)p->d.nnz_inst;
     if (int rc = ensure(&p->d_dense, (size_t)p->nnz())) return rc;
