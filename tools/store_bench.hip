@@ -9,6 +9,14 @@
 #include <cstdlib>
 #include <vector>
 
+typedef double vec2d __attribute__((ext_vector_type(2)));
+// one 16-byte non-temporal store (global_store_dwordx4 ... nt), what the
+// generated kernels' flush issues (there as buffer stores with nt | sc1)
+__device__ inline void store16_nt(void *p, double a, double b) {
+    vec2d v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<vec2d *>(p));
+}
+
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { \
     printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -82,6 +90,43 @@ strip_store(double *out, long long row_doubles, long long nnodes, int G) {
             if (node0 + nd < nnodes && off + 16 <= region) {
                 double2 v = make_double2((double)lane, (double)c);
                 *reinterpret_cast<double2 *>(base + off) = v;
+            }
+        }
+    }
+}
+
+// pattern 2 with non-temporal stores: like the real kernel -- G waves per 64-node block, each writing
+// a strip of every row in SEG-byte pieces whose boundaries are aligned to
+// ALIGNB bytes (flat address), XCD-aware block placement.
+template <int SEG, int ALIGNB>
+__global__ void __launch_bounds__(64)
+strip_store_nt(double *out, long long row_doubles, long long nnodes, int G) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    if (G < 0) lds[lane] = 1.0;
+    const long long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long blk = (slot/G)*8 + xcd;
+    const int g = (int)(slot % G);
+    const long long node0 = blk*64;
+    if (node0 >= nnodes) return;
+    constexpr int LPN = SEG/16, NPS = 64/LPN;
+    const int sub = lane % LPN, nsel = lane/LPN;
+    const long long row_bytes = row_doubles*8;
+    const long long strip = (row_bytes/G)/SEG*SEG;       // bytes per strip
+    const long long s0 = g*strip, s1 = (g == G - 1) ? row_bytes : s0 + strip;
+    char *base = (char *)out + node0*row_bytes;
+    const long long region = 64*row_bytes;
+    for (long long c = s0; c < s1; c += SEG) {
+#pragma unroll
+        for (int p = 0; p < 64/NPS; ++p) {
+            const int nd = p*NPS + nsel;
+            long long start = nd*row_bytes + c;
+            // first ALIGNB boundary at or after the nominal start
+            long long addr = (long long)base + start;
+            long long al = (addr + ALIGNB - 1)/ALIGNB*ALIGNB - (long long)base;
+            long long off = al + sub*16;
+            if (node0 + nd < nnodes && off + 16 <= region) {
+                store16_nt(base + off, (double)lane, (double)c);
             }
         }
     }
@@ -171,10 +216,7 @@ ticket_store(double *out, long long row_doubles, long long nnodes, int G,
                 long long al = (addr + 127)/128*128 - (long long)base;
                 long long off = al + sub*16;
                 if (node0 + nd < nnodes && off + 16 <= region) {
-                    double2 v = make_double2((double)lane, (double)c);
-                    __builtin_nontemporal_store(v.x, (double *)(base + off));
-                    __builtin_nontemporal_store(v.y,
-                                                (double *)(base + off) + 1);
+                    store16_nt(base + off, (double)lane, (double)c);
                 }
             }
         }
@@ -200,6 +242,15 @@ strided_fill(double2 *out, long long n2, int S) {
     const long long piece = (blockIdx.x % S)*per_stream + blockIdx.x/S;
     const long long i = piece*256 + threadIdx.x;
     if (blockIdx.x/S < per_stream && i < n2) out[i] = make_double2(1.0, 2.0);
+}
+
+__global__ void __launch_bounds__(256)
+strided_fill_nt(double2 *out, long long n2, int S) {
+    const long long pieces = (n2 + 255)/256;
+    const long long per_stream = (pieces + S - 1)/S;
+    const long long piece = (blockIdx.x % S)*per_stream + blockIdx.x/S;
+    const long long i = piece*256 + threadIdx.x;
+    if (blockIdx.x/S < per_stream && i < n2) store16_nt(out + i, 1.0, 2.0);
 }
 
 // plain streaming fill with 64-thread blocks, one 1 KB store per block
@@ -326,6 +377,16 @@ int main(int argc, char **argv) {
                     fflush(stdout);
                 }
         CHECK(hipFree(tickets));
+        // the static XCD-aware dispatch with the same non-temporal stores
+        for (int G : {8, 20, 32}) {
+            if (G > 8 && row < 2000) continue;
+            const int nblk = (int)(((nnodes + 63)/64 + 7)/8*8);
+            float ms = time_ms([&] { hipLaunchKernelGGL(
+                (strip_store_nt<256, 128>), dim3(nblk*G), dim3(64), 36*1024, 0,
+                out, row, nnodes, G); });
+            printf("strips G=%d static dispatch seg256/a128 nt  %.4f ms  "
+                   "%7.0f GB/s\n", G, ms, gb/ms*1e3);
+        }
     }
     const long long n2 = nnodes*arg_row/2;
     for (int nb : {512, 2048, 8192}) {
@@ -339,6 +400,8 @@ int main(int argc, char **argv) {
         const long long per_stream = (pieces + S - 1)/S;
         float ms = time_ms([&] { hipLaunchKernelGGL(strided_fill, dim3((unsigned)(per_stream*S)), dim3(256), 0, 0, (double2 *)out, n2, S); });
         printf("strided_fill streams=%d %.4f ms %7.0f GB/s\n", S, ms, n2*16/1e9/ms*1e3);
+        ms = time_ms([&] { hipLaunchKernelGGL(strided_fill_nt, dim3((unsigned)(per_stream*S)), dim3(256), 0, 0, (double2 *)out, n2, S); });
+        printf("strided_fill streams=%d non-temporal %.4f ms %7.0f GB/s\n", S, ms, n2*16/1e9/ms*1e3);
     }
     {
         float ms = time_ms([&] { hipLaunchKernelGGL(stream_fill64, dim3((unsigned)((n2 + 63)/64)), dim3(64), 0, 0, (double2 *)out, n2); });
