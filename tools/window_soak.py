@@ -20,7 +20,11 @@ bad = total = rounding = 0
 for name, nodes in (('config3_10link_small', 5003),
                     ('gaitlike_3link_be_small', 3001),
                     ('chaplygin_mid_small', 2500),
-                    ('config2_pendulum_small', 4097)):
+                    ('config2_pendulum_small', 4097),
+                    # arithmetic-bound blocks: constraint rows ride in the
+                    # Jacobian waves of the fused kernel (r04)
+                    ('one_legged_small', 2051),
+                    ('elementary_be_small', 3333)):
     factory, fkw = problems.CONFIGS[name]
     col = opty_amd.ConstraintCollocator(**factory(**dict(fkw,
                                                          num_nodes=nodes)))
@@ -36,8 +40,17 @@ for name, nodes in (('config3_10link_small', 5003),
     jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
     hip.eval_con_jac(free, con, jac, hb.DEVICE)
     torch.cuda.synchronize()
-    con2d = con[:M*ncn].view(M, ncn)
-    jac2d = jac[:P*ncn].view(ncn, P)
+    # like with like: the fused kernel's windows against the fused kernel's
+    # whole evaluation, the separate kernels' against theirs (blocks whose
+    # constraint rows ride in the Jacobian waves of the fused kernel evaluate
+    # them with other code than opty_con: a cancelling entry may differ by
+    # more than a rounding between the two)
+    fused_ref = (con[:M*ncn].view(M, ncn).clone(),
+                 jac[:P*ncn].view(ncn, P).clone())
+    hip.eval_con(free, con, hb.DEVICE)
+    hip.eval_jac(free, jac, hb.DEVICE)
+    torch.cuda.synchronize()
+    separate_ref = (con[:M*ncn].view(M, ncn), jac[:P*ncn].view(ncn, P))
     for k in range(count):
         a = rng.randrange(0, ncn)
         b = min(ncn, a + rng.choice([1, 2, 63, 64, 65, 127, 200,
@@ -59,6 +72,7 @@ for name, nodes in (('config3_10link_small', 5003),
             cptr = cbuf
         jbuf = torch.full(((b - a)*P,), float('nan'), dtype=torch.float64,
                           device=dev)
+        con2d, jac2d = fused_ref if what == hb.EVAL_FUSED else separate_ref
         hip.eval_shard(what, free,
                        cptr if what != hb.EVAL_JAC else None, cs,
                        jbuf if what != hb.EVAL_CON else None, a, b)
