@@ -854,6 +854,35 @@ def test_host_pipelines_in_node_windows(name, N, windows, monkeypatch):
                                        atol=1e-12*np.abs(want_j).max())
 
 
+def test_constraint_arrays_are_fresh_to_the_caller():
+    """``constraints(free)`` returns a new array per call as far as the
+    caller can tell (``opty/direct_collocation.py:2444``): results that are
+    kept -- the array or a view of it -- never change afterwards, however
+    many are kept; a result that was dropped may lend its page-locked memory
+    to a later call."""
+    col = _collocator('config2_pendulum_small')
+    con = col.generate_constraint_function()
+    frees = [problems.make_free(col.num_free, seed=s) for s in range(8)]
+    kept = [con(f) for f in frees]              # more than the ring holds
+    copies = [k.copy() for k in kept]
+    views = [con(f)[3:9] for f in frees[:3]]    # only a view survives
+    view_copies = [v.copy() for v in views]
+    for _ in range(3):
+        for f in frees:
+            con(f)                              # dropped at once
+    for k, c in zip(kept, copies):
+        np.testing.assert_array_equal(k, c)
+    for v, c in zip(views, view_copies):
+        np.testing.assert_array_equal(v, c)
+    assert len({id(k) for k in kept}) == len(kept)
+    for k, f in zip(kept, frees):
+        np.testing.assert_array_equal(k, con(f))
+    a = con(frees[0])
+    addr = a.ctypes.data
+    del a
+    assert con(frees[1]).ctypes.data == addr     # recycled when unobserved
+
+
 def test_persistent_jacobian_does_not_trust_a_reused_address():
     """A host vector at the address of an earlier one is NOT taken to hold
     the invariant entries: the closure of ``generate_jacobian_function`` says
