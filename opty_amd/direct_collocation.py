@@ -838,12 +838,6 @@ class ConstraintCollocator(object):
         finally:
             h.close()
 
-    def _compare_builds(self, meta, hsaco_a, hsaco_b, seed=7):
-        """Largest disagreement of two code objects of this problem's module
-        (kernel by kernel) on the first ``_VERIFY_NODES`` nodes."""
-        return self._disagreement(self._evaluate_build(meta, hsaco_a, seed),
-                                  self._evaluate_build(meta, hsaco_b, seed))
-
     def tune_launch(self, **kwargs):
         """Times the neighbouring launch geometries of this problem on the
         device, records the winners in the launch-plan file
