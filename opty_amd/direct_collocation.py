@@ -863,13 +863,15 @@ class ConstraintCollocator(object):
         nodes, relative to the largest value of each vector (rounding level,
         ~1e-15, when both builds are right).
 
-        Why: kernels at the register limit (50-state systems) met an ``-O2``
-        miscompile of the pre-register-allocation scheduler in round 3
-        (DESIGN.md section 4.1).  Builds with its symptom -- vector-register
-        spills -- are never used, and the shipped configurations are tested
-        against the reference; this is the same check for a problem of your
-        own, once, after the first build (the ``-O1`` twin of a 50-state
-        system takes a minute or two to compile).  Needs ``torch``."""
+        A disagreement means that ONE of the two builds is faulty, not
+        which: round 4 met ``-O1`` kernels that were the wrong ones
+        (DESIGN.md section 4.1).  The automatic check every build at the
+        register limit goes through before its handle exists
+        (:meth:`_verify_build`: the build's separate and fused kernels
+        against each other, then against twins until one confirms them)
+        decides that; this method is the same comparison on demand, over
+        larger node windows and with the caller's ``free``.  Needs
+        ``torch``."""
         import torch
         hip = self._ensure_hip()
         meta = self._kernel_meta
