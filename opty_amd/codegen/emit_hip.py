@@ -592,8 +592,11 @@ class _ModuleWriter(object):
         costs = {}
         for a in range(nunits):
             for b in range(a + 1, min(nunits, a + wmax) + 1):
+                width = ends[b] - ends[a]
+                # (the small convex term breaks ties between cuts of a
+                # store-only region: even pieces, not slivers)
                 costs[a, b] = self._weighted_cost(ends[a], ends[b]) + \
-                    STORE_WEIGHT*(ends[b] - ends[a])
+                    STORE_WEIGHT*width + 0.25*STORE_WEIGHT*width*width/P
 
         def solve(bound):
             INF = float('inf')
