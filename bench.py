@@ -218,7 +218,8 @@ def other_configs(dev, iters):
     from examples import problems
     out = {}
     for name in ('config2_pendulum', 'config5_standin_24link',
-                 'config5_gaitlike_24link', 'config5_one_legged'):
+                 'config5_gaitlike_24link', 'config5_one_legged',
+                 'config5_biped'):
         pkw = problems.build(name)
         col = opty_amd.ConstraintCollocator(device=dev.index, **pkw)
         hip = col.hip

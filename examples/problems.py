@@ -458,6 +458,107 @@ def gallery_problem(name='gallery_one_legged_time_trial', num_nodes=None):
     return kw
 
 
+def planar_biped(num_nodes=50000, method='backward euler'):
+    """Config-5-shaped stand-in with the STRUCTURE of the gait model the
+    reference's ``plot_human_gait.py`` takes from ``pygait2d`` (absent here,
+    SURVEY.md 8(c)): a planar seven-segment biped -- trunk, two thighs, two
+    shanks, two feet -- with 9 degrees of freedom (hip position, trunk angle,
+    six joint angles), i.e. 18 states, driven by six joint torques (unknown
+    input trajectories), with a smoothed ground contact under the heel and
+    the toe of each foot (normal force from a smooth ``max(0, -y)`` with
+    damping, smoothed Coulomb friction), a free node time interval and the
+    gait example's periodicity conditions written for half a symmetric
+    stride (left and right swap: two-atom instance constraints).  Derived
+    with Kane's method; implicit first-order form ``[q' - u; F_r + F_r*]``
+    (M = n = 18, q = 6, C = 43, P = 774)."""
+    t = sm.Symbol('t')
+    me.dynamicsymbols._t = t
+    q = list(me.dynamicsymbols('qx qy qa qb qc qd qe qf qg', real=True))
+    u = list(me.dynamicsymbols('ux uy ua ub uc ud ue uf ug', real=True))
+    T = list(me.dynamicsymbols('Tb Tc Td Te Tf Tg', real=True))
+    g, kc, cc, mu, eps = sm.symbols('g kc cc mu eps', real=True)
+    seg = {n: sm.symbols('m_%s I_%s l_%s d_%s' % (n, n, n, n), real=True)
+           for n in ('tr', 'th', 'sh', 'ft')}
+    N = me.ReferenceFrame('N')
+    origin = me.Point('O')
+    origin.set_vel(N, 0)
+    hip = origin.locatenew('hip', q[0]*N.x + q[1]*N.y)
+    hip.set_vel(N, u[0]*N.x + u[1]*N.y)
+    A = N.orientnew('A', 'Axis', (q[2], N.z))
+    A.set_ang_vel(N, u[2]*N.z)
+    bodies, loads = [], []
+
+    def body(name, com, frame, m, inertia):
+        bodies.append(me.RigidBody(name, com, frame, m,
+                                   (me.inertia(frame, 0, 0, inertia), com)))
+        loads.append((com, -m*g*N.y))
+
+    m, I, l, d = seg['tr']
+    com = hip.locatenew('trc', d*A.y)
+    com.v2pt_theory(hip, N, A)
+    body('trunk', com, A, m, I)
+    for side, k in (('r', 3), ('l', 6)):
+        frames, parent = [], A
+        for j in range(3):
+            F = parent.orientnew('F%s%d' % (side, j), 'Axis',
+                                 (q[k + j], parent.z))
+            F.set_ang_vel(parent, u[k + j]*parent.z)
+            loads.extend([(F, T[k - 3 + j]*N.z), (parent, -T[k - 3 + j]*N.z)])
+            frames.append(F)
+            parent = F
+        B, C, D = frames
+        (m1, I1, l1, d1), (m2, I2, l2, d2), (m3, I3, l3, d3) = (
+            seg['th'], seg['sh'], seg['ft'])
+        thc = hip.locatenew('thc' + side, -d1*B.y)
+        knee = hip.locatenew('knee' + side, -l1*B.y)
+        for pnt in (thc, knee):
+            pnt.v2pt_theory(hip, N, B)
+        shc = knee.locatenew('shc' + side, -d2*C.y)
+        ankle = knee.locatenew('ankle' + side, -l2*C.y)
+        for pnt in (shc, ankle):
+            pnt.v2pt_theory(knee, N, C)
+        ftc = ankle.locatenew('ftc' + side, d3*D.x)
+        heel = ankle.locatenew('heel' + side, -l3/4*D.x - l3/5*D.y)
+        toe = ankle.locatenew('toe' + side, 3*l3/4*D.x - l3/5*D.y)
+        for pnt in (ftc, heel, toe):
+            pnt.v2pt_theory(ankle, N, D)
+        body('th' + side, thc, B, m1, I1)
+        body('sh' + side, shc, C, m2, I2)
+        body('ft' + side, ftc, D, m3, I3)
+        for pnt in (heel, toe):
+            y = pnt.pos_from(origin).dot(N.y)
+            vx, vy = pnt.vel(N).dot(N.x), pnt.vel(N).dot(N.y)
+            normal = kc*(sm.sqrt(y**2 + eps**2) - y)/2*(1 - cc*vy)
+            loads.append((pnt, normal*N.y -
+                          mu*normal*vx/sm.sqrt(vx**2 + eps**2)*N.x))
+    kd = [qi.diff(t) - ui for qi, ui in zip(q, u)]
+    kane = me.KanesMethod(N, q, u, kd_eqs=kd)
+    fr, frstar = kane.kanes_equations(bodies, loads)
+    eom = sm.Matrix(kd).col_join(fr + frstar)
+    values = {'g': 9.81, 'kc': 2.0e3, 'cc': 0.5, 'mu': 0.8, 'eps': 0.02,
+              'm_tr': 50.0, 'I_tr': 3.2, 'l_tr': 0.6, 'd_tr': 0.3,
+              'm_th': 7.0, 'I_th': 0.15, 'l_th': 0.44, 'd_th': 0.19,
+              'm_sh': 3.4, 'I_sh': 0.05, 'l_sh': 0.43, 'd_sh': 0.19,
+              'm_ft': 1.0, 'I_ft': 0.005, 'l_ft': 0.2, 'd_ft': 0.06}
+    par_map = {s: values[s.name] for s in sorted(
+        (s for s in eom.free_symbols if s != t), key=lambda s: s.name)}
+    h = sm.Symbol('h', real=True)
+    dur = (num_nodes - 1)*h
+    f = lambda x, when: x.func(when)
+    swap = [(3, 6), (4, 7), (5, 8), (6, 3), (7, 4), (8, 5)]
+    inst = [f(q[0], 0*h), f(q[1], 0*h) - f(q[1], dur),
+            f(q[2], 0*h) - f(q[2], dur)]
+    inst += [f(q[a], 0*h) - f(q[b], dur) for a, b in swap]
+    inst += [f(u[k], 0*h) - f(u[k], dur) for k in range(3)]
+    inst += [f(u[a], 0*h) - f(u[b], dur) for a, b in swap[:3]]
+    inst += [f(T[0], 0*h) - f(T[3], dur)]
+    return dict(equations_of_motion=eom, state_symbols=tuple(q + u),
+                num_collocation_nodes=num_nodes, node_time_interval=h,
+                known_parameter_map=par_map,
+                instance_constraints=tuple(inst), time_symbol=t,
+                integration_method=method)
+
+
 # name -> (factory, kwargs).  "*_small" variants are the sizes the oracle and
 # the reference finish in seconds; parity fixtures are generated from them.
 CONFIGS = {
@@ -521,6 +622,9 @@ CONFIGS = {
     'config5_gaitlike_24link': (gait_like_pendulum, {}),
     'config5_gaitlike_24link_small': (gait_like_pendulum, {'num_nodes': 6}),
     # a real muscle-driven DAE with a reference golden (config-5 class)
+    # seven-segment planar biped: the structure of the gait model of config 5
+    'biped_small': (planar_biped, {'num_nodes': 9}),
+    'config5_biped': (planar_biped, {}),
     'one_legged_small': (gallery_problem, {'num_nodes': 43}),
     'config5_one_legged': (gallery_problem, {'num_nodes': 50000}),
 }

@@ -33,6 +33,7 @@ TARGETS = [
      (1, 8)),
     ('config2_pendulum', 'config2_pendulum_small', 10000, (1,)),
     ('config5_one_legged', 'one_legged_small', 50000, (1, 8)),
+    ('config5_biped', 'biped_small', 50000, (1, 8)),
 ] + [(name, name, ZOO_NODES, (1,)) for name in (
     'pend3_link_midpoint_small', 'delay_be_small', 'odd_block_mid_small',
     'chaplygin_be_small', 'elementary_be_small',
