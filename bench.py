@@ -220,73 +220,85 @@ def other_configs(dev, iters):
     for name in ('config2_pendulum', 'config5_standin_24link',
                  'config5_gaitlike_24link', 'config5_one_legged',
                  'config5_biped'):
-        pkw = problems.build(name)
-        col = opty_amd.ConstraintCollocator(device=dev.index, **pkw)
-        hip = col.hip
-        hip.use_torch_stream()
-        free = torch.from_numpy(problems.make_free(
-            col.num_free, variable_duration=col._variable_duration)).to(dev)
-        con = torch.empty(col.num_constraints, dtype=torch.float64,
-                          device=dev)
-        jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
-        res = {}
-        for what, label in ((hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC,
-                                                        'opty_jac'),
-                            (hb.EVAL_FUSED, 'opty_conjac')):
-            hip.time_eval(what, free, con, jac, max(3, iters//4))
-            res[label] = hip.time_eval(what, free, con, jac, iters)
-        nbytes = 8.0*(col.num_free + col.num_constraints + hip.nnz)
-        out[name] = dict(
-            nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
-            fused_algorithmic_bytes=nbytes,
-            fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
-        if name.startswith('config5'):
-            # one of eight node shards of the same problem (what each GPU of
-            # an 8-GPU node launches): its own launch geometry, the global
-            # free vector, a node range from the middle
-            from opty_amd.sharded import partition_nodes
-            ncn = col.num_collocation_nodes - 1
-            a, b = partition_nodes(ncn, 8)[3]
-            shard = opty_amd.ConstraintCollocator(
-                device=dev.index, launch_nodes=b - a, **pkw)
-            shard._program = col._program            # same equations
-            sh = shard.hip
-            sh.use_torch_stream()
-            prog = col._build_program()
-            scon = torch.empty((prog.M, b - a), dtype=torch.float64,
-                               device=dev)
-            sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a, jac, a, b,
-                               max(3, iters//4))
-            ms = min(sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a,
-                                        jac, a, b, iters) for _ in range(3))
-            out[name]['shard_1of8'] = dict(
-                nodes=b - a, fused_ms=ms,
-                speedup_vs_whole=res['opty_conjac']/ms)
-            sh.close()
-            del scon
-        if name == 'config2_pendulum':
-            # the cyipopt-callback path of the small config (NumPy in / out,
-            # PCIe and sync latency inclusive); the reference's compiled C
-            # takes 140 us + 189 us on one core
-            import numpy as np
-            hip.set_stream(None)
-            cf = col.generate_constraint_function()
-            jf = col.generate_jacobian_function()
-            hf = [problems.make_free(col.num_free, seed=s) for s in range(3)]
-            lat = {}
-            for label, fn in (('con', cf), ('jac', jf)):
-                fn(hf[0])
-                ts = []
-                for k in range(50):
-                    t0 = time.perf_counter()
-                    fn(hf[k % 3])
-                    ts.append(time.perf_counter() - t0)
-                lat[label] = 1e6*float(np.median(ts))
-            out[name]['host_path_us'] = lat
-        hip.close()
-        del con, jac, free
-        torch.cuda.empty_cache()
+        try:
+            _other_config(name, dev, iters, out, torch, opty_amd, hb,
+                          problems)
+        except Exception as exc:     # noqa: the headline line must survive
+            # (a build that the verification of DESIGN.md 4.1 refuses, a
+            # problem that does not fit ...): recorded, not fatal
+            out[name] = {'error': '%s: %s' % (type(exc).__name__,
+                                             str(exc)[:600])}
+            torch.cuda.empty_cache()
     return out
+
+
+def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
+    pkw = problems.build(name)
+    col = opty_amd.ConstraintCollocator(device=dev.index, **pkw)
+    hip = col.hip
+    hip.use_torch_stream()
+    free = torch.from_numpy(problems.make_free(
+        col.num_free, variable_duration=col._variable_duration)).to(dev)
+    con = torch.empty(col.num_constraints, dtype=torch.float64,
+                      device=dev)
+    jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
+    res = {}
+    for what, label in ((hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC,
+                                                    'opty_jac'),
+                        (hb.EVAL_FUSED, 'opty_conjac')):
+        hip.time_eval(what, free, con, jac, max(3, iters//4))
+        res[label] = hip.time_eval(what, free, con, jac, iters)
+    nbytes = 8.0*(col.num_free + col.num_constraints + hip.nnz)
+    out[name] = dict(
+        nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
+        fused_algorithmic_bytes=nbytes,
+        fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
+    if name.startswith('config5'):
+        # one of eight node shards of the same problem (what each GPU of
+        # an 8-GPU node launches): its own launch geometry, the global
+        # free vector, a node range from the middle
+        from opty_amd.sharded import partition_nodes
+        ncn = col.num_collocation_nodes - 1
+        a, b = partition_nodes(ncn, 8)[3]
+        shard = opty_amd.ConstraintCollocator(
+            device=dev.index, launch_nodes=b - a, **pkw)
+        shard._program = col._program            # same equations
+        sh = shard.hip
+        sh.use_torch_stream()
+        prog = col._build_program()
+        scon = torch.empty((prog.M, b - a), dtype=torch.float64,
+                           device=dev)
+        sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a, jac, a, b,
+                           max(3, iters//4))
+        ms = min(sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a,
+                                    jac, a, b, iters) for _ in range(3))
+        out[name]['shard_1of8'] = dict(
+            nodes=b - a, fused_ms=ms,
+            speedup_vs_whole=res['opty_conjac']/ms)
+        sh.close()
+        del scon
+    if name == 'config2_pendulum':
+        # the cyipopt-callback path of the small config (NumPy in / out,
+        # PCIe and sync latency inclusive); the reference's compiled C
+        # takes 140 us + 189 us on one core
+        import numpy as np
+        hip.set_stream(None)
+        cf = col.generate_constraint_function()
+        jf = col.generate_jacobian_function()
+        hf = [problems.make_free(col.num_free, seed=s) for s in range(3)]
+        lat = {}
+        for label, fn in (('con', cf), ('jac', jf)):
+            fn(hf[0])
+            ts = []
+            for k in range(50):
+                t0 = time.perf_counter()
+                fn(hf[k % 3])
+                ts.append(time.perf_counter() - t0)
+            lat[label] = 1e6*float(np.median(ts))
+        out[name]['host_path_us'] = lat
+    hip.close()
+    del con, jac, free
+    torch.cuda.empty_cache()
 
 
 def host_path(kw, dev_index, reps=7):
