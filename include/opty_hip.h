@@ -390,6 +390,16 @@ int opty_hip_host_free(void *ptr);
 int opty_hip_host_register(void *ptr, size_t bytes);
 int opty_hip_host_unregister(void *ptr);
 
+/* Build verification (no reference counterpart: the reference trusts its C
+ * compiler).  Evaluates an instruction tape of a problem's expression DAG
+ * (opty_amd/codegen/tape.py: 8 int32 per instruction -- op, dst, a, b, c, d,
+ * imm, 0) on `device`, one lane per node, over the HOST value table
+ * vals[slot*nodes + node] (uploaded, run, downloaded in place; constant and
+ * input slots pre-filled by the caller).  What the generated kernels of a code
+ * object at the register limit are held to before a handle exists. */
+int opty_hip_tape_run(int32_t device, const int32_t *code, int64_t ninstr,
+                      double *vals, int64_t nslots, int64_t nodes);
+
 int opty_hip_device_count(void);
 const char *opty_hip_last_error(void);
 

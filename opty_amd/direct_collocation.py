@@ -129,6 +129,9 @@ class ConstraintCollocator(object):
         # launch plan of this problem and launch size, else the printer's own
         # rules
         self._emit_options = emit_options
+        self._pinned = None         # (EmitOptions, hipcc switches), see
+        #                             _verified_alternative
+        self._built_options = None
 
         self._sort_parameters()
         self._sort_trajectories()
@@ -563,12 +566,24 @@ class ConstraintCollocator(object):
         count, then the strips of the spilling kernels are made narrower,
         until a build is spill-free."""
         import copy
+        pinned = self._pinned_build()
+        if pinned is not None and opt_level is None:
+            # a build that replaced one the verification refused
+            # (_verified_alternative): reproduced exactly as recorded
+            opts, how = pinned
+            source, meta = self._emit(opts)
+            hsaco = hb.compile_module(
+                source, self.tmp_dir, self.show_compile_output,
+                opt_level=how.get('opt_level'),
+                extra_flags=tuple(how.get('extra_flags', ())))
+            self._built_source, self._built_options = source, opts
+            return hsaco, meta
         opts = self._printer_options()
         source, meta = self._emit(opts)
         hsaco = hb.compile_module(source, self.tmp_dir,
                                   self.show_compile_output,
                                   opt_level=opt_level)
-        self._built_source = source
+        self._built_source, self._built_options = source, opts
         if self._emit_options is not None:
             # the caller fixed the geometry: it is built as asked, but never
             # silently -- this is the build class that returned wrong values
@@ -580,7 +595,7 @@ class ConstraintCollocator(object):
                     'values (DESIGN.md 4.1): drop emit_options, or verify '
                     'with ConstraintCollocator.cross_check()', spills)
             return hsaco, meta
-        best = (hsaco, meta, hb.vgpr_spills(hsaco), (source, meta))
+        best = (hsaco, meta, hb.vgpr_spills(hsaco), (source, meta), opts)
         geo = meta['geometry']
         # where spills appear is erratic in the cut (24-link stand-in, fused
         # strips 18 ... 28: only 20, 25 and 28 are spill-free), so the
@@ -618,7 +633,7 @@ class ConstraintCollocator(object):
             hsaco = hb.compile_module(source, self.tmp_dir,
                                       self.show_compile_output,
                                       opt_level=opt_level)
-            return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta)
+            return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta), trial
 
         from concurrent.futures import ThreadPoolExecutor
         phases = [(False, False, list(steps))]
@@ -666,113 +681,195 @@ class ConstraintCollocator(object):
                            best[2], self.num_states, self._program.P,
                            self._launch_blocks(),
                            ' '.join(hb.SAFE_SCHEDULER_FLAGS))
-            self._built_source = source
+            self._built_source, self._built_options = source, best[4]
             return hsaco, meta
-        self._built_source = best[3][0]
+        self._built_source, self._built_options = best[3][0], best[4]
         return best[0], best[1]
 
+    def _pinned_build(self):
+        """``(EmitOptions, {'opt_level': .., 'extra_flags': ..})`` of the
+        build that replaced one the verification refused -- found by this
+        collocator (:meth:`_verified_alternative`) or recorded in the plan
+        file (``"pinned"`` entries of ``launch_plans.json``) -- or None."""
+        if self._emit_options is not None:
+            return None
+        if self._pinned is not None:
+            return self._pinned
+        from . import launch_plan
+        entry = launch_plan.lookup_entry(self._build_program(),
+                                         self._launch_blocks())
+        if entry and entry.get('pinned') is not None:
+            try:
+                return EmitOptions(**entry['options']), dict(entry['pinned'])
+            except (TypeError, AssertionError, KeyError):
+                return None             # written by another printer version
+        return None
+
+    def _verified_alternative(self, refused, meta, err):
+        """Another build of this problem's kernels that the verification
+        accepts, after it refused ``refused`` (:meth:`_verify_build`).
+
+        hipcc's faults at the register limit are erratic in the cut -- the
+        biped's default 20 strips are wrong in strip 17, identically in both
+        Jacobian kernels, while 12, 24 and 32 strips, 16-entry chunks and the
+        other ``sincos`` are right -- so the neighbouring geometries are
+        tried in the order of their expected cost (strips +2, +4, +1, +6 ...,
+        then ``fast_trig``, 16-entry chunks, then the same source through
+        ``-O1`` and without the pre-RA stage of round 3), several compiled at
+        a time, each held to the instruction tape; the first accepted one is
+        used, remembered by this collocator and recorded in the plan file as
+        a ``"pinned"`` entry (``__graft_entry__.build`` prebuilds those).
+        Raises ``err`` when nothing passes."""
+        import copy
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        from . import launch_plan
+        base = self._built_options
+        geo = meta['geometry']
+        cands = []
+        if geo['line_mode'] or self._jacobian_layout == 'csr':
+            for d in (2, 4, 1, 6, 8, 12, -2, -4):
+                if min(geo['jac'], geo['fused']) + d >= 1:
+                    cands.append(('strips%+d' % d, dict(
+                        groups=geo['jac'] + d, fused_groups=geo['fused'] + d),
+                        {}))
+        if not base.fast_trig:
+            cands.append(('fast_trig', dict(fast_trig=1), {}))
+        if geo['line_mode'] and base.chunk == 32:
+            cands.append(('chunk16', dict(chunk=16), {}))
+        cands += [('-O1', {}, dict(opt_level='-O1')),
+                  ('no-hp-reschedule', {},
+                   dict(extra_flags=list(hb.SAFE_SCHEDULER_FLAGS)))]
+
+        def build(cand):
+            label, okw, how = cand
+            opts = copy.copy(base)
+            for k, v in okw.items():
+                setattr(opts, k, v)
+            source, m = self._emit(opts)
+            hsaco = hb.compile_module(
+                source, self.tmp_dir, self.show_compile_output,
+                opt_level=how.get('opt_level'),
+                extra_flags=tuple(how.get('extra_flags', ())))
+            return label, opts, how, source, m, hsaco
+
+        tried = [(os.path.basename(refused), err.verdict['errors'])]
+        while cands:
+            batch, cands = cands[:4], cands[4:]
+            with ThreadPoolExecutor(len(batch)) as pool:
+                built = list(pool.map(build, batch))
+            for label, opts, how, source, m, hsaco in built:
+                if hsaco == refused:
+                    continue
+                self._built_source, self._built_options = source, opts
+                try:
+                    verdict = self._verify_build(hsaco, m, force=True)
+                except hb.BuildRejected as again:
+                    tried.append((label, again.verdict['errors']))
+                    continue
+                logger.warning(
+                    'the default build of this problem\'s kernels (%s) was '
+                    'refused by the verification (%s); using %s (%s) instead',
+                    os.path.basename(refused), err.verdict['errors'], label,
+                    os.path.basename(hsaco))
+                verdict = dict(verdict, replaces=os.path.basename(refused),
+                               replacement=label, refused=tried)
+                self._pinned = (opts, how)
+                try:
+                    launch_plan.record(
+                        launch_plan.key_of(self._build_program(),
+                                           self._launch_blocks()),
+                        dict(options=launch_plan.options_kwargs(opts),
+                             pinned=dict(how, label=label,
+                                         replaces=os.path.basename(refused)),
+                             refused=tried,
+                             nodes=self._launch_nodes or
+                             self.num_collocation_nodes - 1,
+                             problem='%d states, %d entries per block'
+                             % (self.num_states, self._program.P)))
+                except OSError:
+                    pass
+                return hsaco, m, verdict
+        raise hb.BuildRejected(
+            '%s  No neighbouring build passes either: %s' % (err, tried),
+            err.verdict)
+
     def prebuild(self):
-        """Builds everything :meth:`_ensure_hip` will want, without a device:
-        the code object and, for kernels at the register limit, the twins
-        that :meth:`_verify_build` compares it with.  Returns ``(hsaco,
+        """Builds what :meth:`_ensure_hip` will load, without a device: the
+        code object of the printer's choice -- or, when the plan file holds a
+        ``"pinned"`` entry for this problem (a build that replaced one the
+        verification refused), exactly that one.  Returns ``(hsaco,
         meta)``."""
-        hsaco, meta = self._build_code_object()
-        if hb.high_pressure_kernels(hsaco):
-            hb.compile_module(self._built_source, self.tmp_dir,
-                              self.show_compile_output, opt_level='-O1')
-            hb.compile_module(self._built_source, self.tmp_dir,
-                              self.show_compile_output,
-                              extra_flags=hb.SAFE_SCHEDULER_FLAGS)
-        return hsaco, meta
+        return self._build_code_object()
 
     #: nodes the automatic check below evaluates (``OPTY_CROSS_CHECK=off``
-    #: disables it)
+    #: disables it, ``=all`` extends it to every build)
     _VERIFY_NODES = 131
+    _VERIFY_RTOL = 1e-9
 
-    def _verify_build(self, hsaco, meta):
-        """Checks a build whose kernels sit at the edge of the register file
+    def _verify_build(self, hsaco, meta, force=False):
+        """Holds a build whose kernels sit at the edge of the register file
         (``hip_backend.high_pressure_kernels``: >= 480 VGPRs or spilled
-        SGPRs) before the handle is handed out; raises
-        :class:`hip_backend.HipBackendError` when it cannot be confirmed.
+        SGPRs) to the expression DAG itself before the handle is handed out;
+        raises :class:`hip_backend.BuildRejected` when a kernel disagrees.
 
         Why: hipcc 7.2 has produced code objects of exactly such kernels
-        whose values are wrong (deterministically, at every node): ``-O2``
-        schedules with vector spills in round 3, and in round
-        4 an ``-O1`` build WITHOUT vector spills (504 VGPRs, 373 spilled
-        SGPRs: the row-sorted Jacobian kernel of the muscle-driven leg, 2.7 %
-        off in one strip).  "No vector spills" is a symptom fence; this is
-        the check itself, a consensus of independently compiled kernels:
-
-        1. the build's own two Jacobian kernels -- ``opty_jac`` and the fused
-           ``opty_conjac``, different cuts of the same expressions compiled
-           separately -- must agree with each other (and its two constraint
-           kernels likewise);
-        2. one kernel of a *twin* -- the SAME generated source through
-           another compiler pipeline: ``-O1``, then ``-O2`` without the
-           scheduler stage implicated in round 3 -- must agree with them.  A
-           twin that disagrees with itself is discarded (it is the faulty
-           one).
-
-        Everything evaluates the first ``_VERIFY_NODES`` nodes of the problem
-        (two full waves and a ragged one; the kernels do not depend on N) on
-        seeded values.  The verdict is remembered next to the code object
-        (``<hsaco>.crosscheck.json``); the twins are cached by source hash
-        like every build (``__graft_entry__.build`` prebuilds the first)."""
+        whose values are wrong, deterministically and in whole strips:
+        ``-O2`` schedules with vector spills in round 3, an
+        ``-O1`` build WITHOUT vector spills in round 4 (504 VGPRs, 373
+        spilled SGPRs: 2.7 % off in one strip), and then a spill-free ``-O2``
+        build of the seven-segment biped whose separate AND fused kernels
+        returned the same wrong strip, confirmed by a twin from another
+        pipeline -- builds cannot vouch for each other.  The referee is
+        ``opty_hip_tape_run``: the DAG as an instruction tape
+        (``codegen/tape.py``) executed on the GPU by one small hand-written
+        kernel of the runtime library, one lane per node, every value in
+        HBM, the same device math library -- nothing for a register
+        allocator to get wrong.  ``opty_con``, ``opty_jac`` and both outputs
+        of ``opty_conjac`` must agree with it on the first ``_VERIFY_NODES``
+        nodes (two full waves and a ragged one; the kernels do not depend on
+        N and every wrong build was wrong at every node) to ``_VERIFY_RTOL``
+        of the largest value of the equation's row.  The verdict is
+        remembered next to the code object (``<hsaco>.crosscheck.json``)."""
         import json
         import os
-        if os.environ.get('OPTY_CROSS_CHECK', '').lower() == 'off':
+        mode = os.environ.get('OPTY_CROSS_CHECK', '').lower()
+        if mode == 'off':
             return None
         hot = hb.high_pressure_kernels(hsaco)
-        if not hot:
+        if not hot and mode != 'all' and not force:
             return None
         side = hsaco + '.crosscheck.json'
         try:
             with open(side) as f:
                 verdict = json.load(f)
-            if verdict.get('ok') is True:
+            if verdict.get('ok') is True and verdict.get('referee') == 'tape':
                 return verdict
         except (OSError, ValueError):
             pass
         logger.info('kernels %s are at the register limit: checking the '
-                    'build', hot)
-        tol = self._VERIFY_RTOL
-        mine = self._evaluate_build(meta, hsaco)
-        own = self._disagreement(mine[:2], mine[2:])
-        verdict = dict(ok=False, own=own, worst=own,
-                       kernels={k: list(v) for k, v in hot.items()},
-                       twins=[])
-        if own > tol:
-            raise hb.HipBackendError(
-                'the separate and the fused kernels of %s (%s) disagree by '
-                '%.3g relative: a compiler fault (DESIGN.md 4.1).  Rebuild '
-                'with other emit_options or OPTY_HIPCC_OPT=-O1.'
-                % (os.path.basename(hsaco), hot, own))
-        for label, kwargs in (('-O1', dict(opt_level='-O1')),
-                              ('no-hp-reschedule', dict(
-                                  extra_flags=hb.SAFE_SCHEDULER_FLAGS))):
-            twin = hb.compile_module(self._built_source, self.tmp_dir,
-                                     self.show_compile_output, **kwargs)
-            theirs = self._evaluate_build(meta, twin)
-            # each of the twin's kernels against the build's
-            sep = self._disagreement(mine[:2], theirs[:2])
-            fused = self._disagreement(mine[:2], theirs[2:])
-            verdict['twins'].append(dict(
-                build=label, file=os.path.basename(twin), separate=sep,
-                fused=fused, own=self._disagreement(theirs[:2], theirs[2:])))
-            if min(sep, fused) <= tol:
-                verdict.update(ok=True, worst=max(own, min(sep, fused)),
-                               confirmed_by=label)
-                break
-            logger.warning('the %s twin of %s disagrees with it (%.3g / '
-                           '%.3g relative) and with itself by %.3g',
-                           label, os.path.basename(hsaco), sep, fused,
-                           verdict['twins'][-1]['own'])
+                    'build against the instruction tape', hot)
+        con, jac, con2, jac2 = self._evaluate_build(meta, hsaco)
+        rcon, rjac, con_row, jac_row = self._reference_values()
+        errors = {
+            'opty_con': self._row_error(con, rcon, con_row),
+            'opty_jac': self._row_error(jac, rjac, jac_row),
+            'opty_conjac': max(self._row_error(con2, rcon, con_row),
+                               self._row_error(jac2, rjac, jac_row))}
+        worst = max(errors.values())
+        verdict = dict(ok=bool(worst <= self._VERIFY_RTOL), referee='tape',
+                       worst=worst, errors=errors, nodes=int(
+                           min(self.num_collocation_nodes,
+                               self._VERIFY_NODES)),
+                       kernels={k: list(v) for k, v in hot.items()})
         if not verdict['ok']:
-            raise hb.HipBackendError(
-                'no other build of this problem\'s kernels confirms %s (%s): '
-                '%s -- a compiler fault in one of them (DESIGN.md 4.1).  '
-                'Rebuild with other emit_options.'
-                % (os.path.basename(hsaco), hot, verdict['twins']))
+            raise hb.BuildRejected(
+                'kernels of %s (%s) disagree with the expression DAG '
+                'evaluated by opty_hip_tape_run: %s (relative to the largest '
+                'value of the equation) -- a compiler fault (DESIGN.md 4.1).'
+                % (os.path.basename(hsaco), hot or 'not at the register '
+                   'limit', {k: '%.3g' % v for k, v in errors.items()}),
+                verdict)
         try:
             tmp = side + '.%d.tmp' % os.getpid()
             with open(tmp, 'w') as f:
@@ -782,27 +879,24 @@ class ConstraintCollocator(object):
             pass
         return verdict
 
-    _VERIFY_RTOL = 1e-9
-
     @staticmethod
-    def _disagreement(xs, ys):
-        """Largest difference of paired vectors relative to the largest value
-        of each pair (inf for non-finite differences)."""
-        worst = 0.0
-        for x, y in zip(xs, ys):
-            if not x.size:
-                continue
-            scale = max(float(np.abs(x).max()), float(np.abs(y).max()),
-                        1e-300)
-            d = np.abs(x - y)
-            worst = max(worst, float(d.max())/scale
-                        if np.isfinite(d).all() else np.inf)
-        return worst
+    def _row_error(got, want, row):
+        """Largest difference between two vectors relative to the largest
+        reference value of the entry's own equation (inf for non-finite
+        values); ``row[k]`` = equation of entry ``k``."""
+        if not want.size:
+            return 0.0
+        d = np.abs(got - want)
+        if not np.isfinite(d).all():
+            return float('inf')
+        scale = np.zeros(int(row.max()) + 1)
+        np.maximum.at(scale, row, np.abs(want))
+        scale = np.maximum(scale, 1e-300)
+        return float((d/scale[row]).max())
 
-    def _evaluate_build(self, meta, hsaco, seed=7):
-        """``[con, jac, fused con, fused jac]`` of one code object of this
-        problem's module on the first ``_VERIFY_NODES`` nodes: separate and
-        fused launches, host buffers, no instance tails (scalar code)."""
+    def _verification_inputs(self, seed=7):
+        """``(N, free)`` of the small problem the verification evaluates:
+        the first ``_VERIFY_NODES`` nodes, seeded values."""
         N = min(self.num_collocation_nodes, self._VERIFY_NODES)
         n, q = self.num_states, self.num_unknown_input_trajectories
         rng = np.random.default_rng(seed)
@@ -810,6 +904,66 @@ class ConstraintCollocator(object):
                            + int(self._variable_duration))
         if self._variable_duration:
             free[-1] = 0.01
+        return N, free
+
+    def _reference_values(self, seed=7):
+        """Constraints and Jacobian values of the verification problem from
+        the instruction tape run on the device (``opty_hip_tape_run``), in
+        the layouts the kernels write: ``(con, jac, con_row, jac_row)``,
+        ``*_row[k]`` = equation of entry ``k``."""
+        from .codegen.tape import Tape
+        prog = self._build_program()
+        N, free = self._verification_inputs(seed)
+        ncn = N - 1
+        n, q = prog.n, prog.q
+        known = self._known_trajectory_array(np.ones(self.num_free))[:, :N] \
+            if self.num_known_input_trajectories else None
+        tail = free[(n + q)*N:]
+        kpar = [float(self.known_parameter_map[p])
+                for p in self.known_parameters]
+
+        def inputs(kind, idx):
+            if kind in ('cur', 'adj'):
+                src, k = prog.rows[idx]
+                row = free[k*N:(k + 1)*N] if src == 'free' else known[k]
+                off = prog.cur_offset if kind == 'cur' else prog.adj_offset
+                return row[off:off + ncn]
+            if kind == 'par':
+                src, k = prog.pars[idx]
+                return kpar[k] if src == 'known' else tail[k]
+            assert kind == 'h', kind
+            return self.node_time_interval if prog.h[0] == 'fixed' \
+                else tail[prog.h[1]]
+
+        roots = list(prog.con_out) + list(prog.jac_out)
+        tape = Tape(prog.dag, roots)
+        vals = hb.tape_run(tape, tape.table(ncn, inputs), self._device)
+        M, P = prog.M, prog.P
+        con = np.concatenate([vals[tape.slot[r]] for r in prog.con_out]) \
+            if M else np.zeros(0)
+        con_row = np.repeat(np.arange(M), ncn)
+        block = np.stack([vals[tape.slot[r]] for r in prog.jac_out], axis=1) \
+            if P else np.zeros((ncn, 0))                # (ncn, P)
+        ent_row = np.array([j for j, _ in prog.pattern], dtype=np.int64)
+        if self._jacobian_layout == 'csr':
+            # jac[S_j*ncn + i*L_j + pos] (DESIGN.md 4.6)
+            jac = np.empty(ncn*P)
+            jac_row = np.empty(ncn*P, dtype=np.int64)
+            rs = prog.row_start
+            for j in range(M):
+                S, L = rs[j], rs[j + 1] - rs[j]
+                jac[S*ncn:(S + L)*ncn] = block[:, S:S + L].ravel()
+                jac_row[S*ncn:(S + L)*ncn] = j
+        else:
+            jac = block.ravel()
+            jac_row = np.tile(ent_row, ncn)
+        return con, jac, con_row, jac_row
+
+    def _evaluate_build(self, meta, hsaco, seed=7):
+        """``[con, jac, fused con, fused jac]`` of one code object of this
+        problem's module on the first ``_VERIFY_NODES`` nodes: separate and
+        fused launches, host buffers, no instance tails (scalar code)."""
+        N, free = self._verification_inputs(seed)
         desc = dict(self._descriptor(meta), N=N, num_inst=0, nnz_inst=0,
                     num_inst_atoms=0, inst_folded=0)
         if self._jacobian_layout == 'varying_first':
@@ -967,7 +1121,13 @@ class ConstraintCollocator(object):
             return self._hip
         logger.info('Compiling the HIP constraint/Jacobian kernels.')
         hsaco, meta = self._build_code_object()
-        self._build_verdict = self._verify_build(hsaco, meta)
+        try:
+            self._build_verdict = self._verify_build(hsaco, meta)
+        except hb.BuildRejected as err:
+            if self._emit_options is not None or self._pinned is not None:
+                raise               # the caller fixed the geometry
+            hsaco, meta, self._build_verdict = self._verified_alternative(
+                hsaco, meta, err)
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
         self._install_tables(hip)
         self._kernel_meta = meta

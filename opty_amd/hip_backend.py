@@ -38,6 +38,16 @@ class HipBackendError(RuntimeError):
     pass
 
 
+class BuildRejected(HipBackendError):
+    """A code object whose kernels disagree with the expression DAG on the
+    verification nodes (``ConstraintCollocator._verify_build``); ``verdict``
+    holds the per-kernel errors."""
+
+    def __init__(self, message, verdict=None):
+        HipBackendError.__init__(self, message)
+        self.verdict = verdict
+
+
 def torch_stream_pointer(stream=None):
     """``hipStream_t`` of a ``torch.cuda.Stream`` (default: the current one)
     for the ``set_stream`` calls.  torch's default stream is the legacy null
@@ -343,6 +353,8 @@ _SIGNATURES = {
                                                ctypes.c_int32]),
     'opty_hip_host_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
     'opty_hip_host_free': (ctypes.c_int, [_P]),
+    'opty_hip_tape_run': (ctypes.c_int, [ctypes.c_int32, _P, ctypes.c_int64,
+                                         _P, ctypes.c_int64, ctypes.c_int64]),
     'opty_hip_device_count': (ctypes.c_int, []),
     'opty_hip_last_error': (ctypes.c_char_p, []),
 }
@@ -381,6 +393,20 @@ def load_library():
 def _check(rc):
     if rc != 0:
         raise HipBackendError(load_library().opty_hip_last_error().decode())
+
+
+def tape_run(tape, vals, device=0):
+    """Runs an instruction tape (:mod:`opty_amd.codegen.tape`) on the device
+    over the value table ``vals`` (``(nslots, nodes)`` float64, C order;
+    constant and input slots filled) -- ``opty_hip_tape_run``, the referee of
+    builds at the register limit.  Fills ``vals`` in place and returns it."""
+    code = np.ascontiguousarray(tape.code, dtype=np.int32)
+    assert vals.dtype == np.float64 and vals.flags.c_contiguous
+    assert vals.shape[0] == tape.nslots
+    _check(load_library().opty_hip_tape_run(
+        int(device), code.ctypes.data, code.shape[0], vals.ctypes.data,
+        vals.shape[0], vals.shape[1]))
+    return vals
 
 
 def _ptr(x):

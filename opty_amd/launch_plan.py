@@ -95,6 +95,19 @@ def lookup(prog, node_blocks):
         return None                     # written by another printer version
 
 
+def lookup_entry(prog, node_blocks):
+    """The raw plan entry for this program and launch size, or None."""
+    plans = _load(plan_path())
+    return plans.get(key_of(prog, node_blocks)) if plans else None
+
+
+def options_kwargs(opts):
+    """The keyword arguments that rebuild ``opts``: its attributes that
+    differ from the printer's defaults."""
+    default = vars(EmitOptions())
+    return {k: v for k, v in vars(opts).items() if default.get(k) != v}
+
+
 def record(key, entry, path=None):
     """Merges one entry into the plan file (atomic replace)."""
     path = path or plan_path() or DEFAULT_FILE
@@ -191,6 +204,16 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
     con = torch.empty((prog.M, nodes), **f64)
     jac = torch.empty(nodes*prog.P, **f64)
     handles = []
+    # candidates at the register limit whose values are wrong (hipcc faults,
+    # ConstraintCollocator._verify_build) do not compete
+    rejected = set()
+    for k, (label, kw, meta, hsaco, spills) in enumerate(built):
+        try:
+            col._verify_build(hsaco, meta)
+        except hb.BuildRejected as err:
+            rejected.add(k)
+            if log:
+                log('%-10s refused: %s' % (label, err.verdict['errors']))
     for label, kw, meta, hsaco, spills in built:
         h = hb.HipProblem(col._descriptor(meta), hsaco)
         col._install_tables(h)
@@ -213,6 +236,8 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
                 if {'fused': 'opty_conjac', 'jac': 'opty_jac'}[what] in \
                         built[k][4]:
                     continue            # spills vector registers
+                if k in rejected:
+                    continue
                 times[what][k].append(h.time_eval_shard(
                     sel[what], free, con, nodes, jac, a, b, iters))
     for h in handles:

@@ -770,18 +770,50 @@ def test_hand_set_workgroup_width_is_narrowed_to_the_lds():
 def test_high_pressure_builds_are_marked_for_verification(name, hot):
     """Kernels at the edge of the register file (>= 480 VGPRs or spilled
     SGPRs: the 24-link stand-ins, the musculoskeletal model) are the ones
-    ``ConstraintCollocator._verify_build`` holds to an ``-O1`` twin before a
-    handle is handed out; ``prebuild`` leaves that twin in the cache."""
+    ``ConstraintCollocator._verify_build`` holds to the instruction tape
+    before a handle is handed out."""
     col = ConstraintCollocator(**problems.build(name))
     hsaco, meta = col.prebuild()
     marked = hb.high_pressure_kernels(hsaco)
     assert bool(marked) == hot, marked
-    if hot:
-        # the twin: same source, -O1 -- a cache hit now
-        before = set(os.listdir(os.path.dirname(hsaco)))
-        twin = hb.compile_module(col._built_source, col.tmp_dir,
-                                 opt_level='-O1')
-        assert twin != hsaco and os.path.basename(twin) in before
+
+
+def test_pinned_plans_are_built_exactly_as_recorded(tmp_path, monkeypatch):
+    """A ``"pinned"`` entry of the plan file -- the build that replaced one
+    the verification refused -- is reproduced as recorded (options and hipcc
+    switches), without the spill loop; caller-fixed options ignore it."""
+    from opty_amd import launch_plan
+    from opty_amd.codegen.emit_hip import EmitOptions
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(tmp_path/'plans.json'))
+    kw = problems.build('pend3_link_midpoint_small')
+    col = ConstraintCollocator(tmp_dir=str(tmp_path), **kw)
+    assert col._pinned_build() is None
+    default, _ = col._build_code_object()
+    opts = EmitOptions(groups=3, fused_groups=4, chunk=16)
+    launch_plan.record(
+        launch_plan.key_of(col._build_program(), col._launch_blocks()),
+        dict(options=launch_plan.options_kwargs(opts),
+             pinned=dict(opt_level='-O1', label='test')))
+    assert launch_plan.options_kwargs(opts) == dict(
+        groups=3, fused_groups=4, chunk=16)
+    col2 = ConstraintCollocator(tmp_dir=str(tmp_path), **kw)
+    pinned_opts, how = col2._pinned_build()
+    assert pinned_opts.key() == opts.key() and how['opt_level'] == '-O1'
+    calls = []
+    real = hb.compile_module
+
+    def spy(source, *args, **kwargs):
+        calls.append(kwargs)
+        return real(source, *args, **kwargs)
+    monkeypatch.setattr(hb, 'compile_module', spy)
+    hsaco, meta = col2._build_code_object()
+    assert hsaco != default and len(calls) == 1
+    assert calls[0]['opt_level'] == '-O1'
+    assert meta['geometry']['jac'] == 3 and meta['geometry']['fused'] == 4
+    assert meta['chunk'] == 16
+    col3 = ConstraintCollocator(tmp_dir=str(tmp_path),
+                                emit_options=EmitOptions(), **kw)
+    assert col3._pinned_build() is None
 
 
 def test_spill_loop_falls_back_on_recomputation_per_chunk():

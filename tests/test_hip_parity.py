@@ -921,20 +921,25 @@ def test_persistent_jacobian_does_not_trust_a_reused_address():
 
 
 def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
-    """``_verify_build``: a build at the register limit is confirmed by a
-    consensus of independently compiled kernels before the handle exists --
-    its own separate and fused kernels, then a twin of the same source from
-    another compiler pipeline.  The real build passes (verdict remembered
-    next to the code object); a faulty TWIN is outvoted by the next one; a
-    build that computes something else -- here: the module of slightly
-    different equations, standing in for a miscompiled one -- is refused."""
+    """``_verify_build``: a build at the register limit is held to the
+    expression DAG itself -- the instruction tape run on the GPU by
+    ``opty_hip_tape_run`` -- before the handle exists.  The real build passes
+    (verdict remembered next to the code object); a build that computes
+    something else -- here: the module of slightly different equations,
+    standing in for a miscompiled one -- is replaced by a neighbouring
+    geometry that passes, recorded as a pinned plan; a caller who fixed the
+    geometry gets the error; so does everybody when nothing passes."""
     import opty_amd
     from opty_amd import hip_backend as hb
+    from opty_amd.codegen.emit_hip import EmitOptions
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(tmp_path/'plans.json'))
     kw = problems.build('one_legged_small')
     col = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path), **kw)
     hip = col.hip                      # builds, verifies, creates the handle
     verdict = col._build_verdict
-    assert verdict['ok'] and verdict['worst'] < 1e-12, verdict
+    assert verdict['ok'] and verdict['worst'] < 1e-11, verdict
+    assert verdict['referee'] == 'tape'
+    assert set(verdict['errors']) == {'opty_con', 'opty_jac', 'opty_conjac'}
     assert 'opty_conjac' in verdict['kernels']
     hsaco = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
     assert any(os.path.exists(os.path.join(tmp_path, f + '.crosscheck.json'))
@@ -947,52 +952,101 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
         **dict(kw, equations_of_motion=eom.applyfunc(
             lambda e: e*(1 + 2.0**-20))))
     bad, _ = wrong._build_code_object()
-    real = hb.compile_module
-
-    # (1) the -O1 twin is the faulty one: the second twin confirms the build
-    def o1_is_wrong(source, *args, **kwargs):
-        if kwargs.get('opt_level') == '-O1':
-            return bad
-        return real(source, *args, **kwargs)
-    monkeypatch.setattr(hb, 'compile_module', o1_is_wrong)
-    col2 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'second'),
-                                         **kw)
-    assert col2.hip is not None
-    assert col2._build_verdict['confirmed_by'] == 'no-hp-reschedule'
-    assert col2._build_verdict['twins'][0]['separate'] > 1e-9
-    col2.hip.close()
-    # (2) the build in use is the faulty one: no twin confirms it
-    monkeypatch.setattr(hb, 'compile_module', real)
+    # (1) the build in use is the faulty one: a neighbouring geometry that
+    # passes takes its place and is pinned in the plan file
     col3 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'third'), **kw)
     good, meta = col3._build_code_object()
-    source = col3._built_source
+    source, options = col3._built_source, col3._built_options
+    real_build = col3._build_code_object
 
     def faulty_build(opt_level=None):
-        col3._built_source = source
+        if col3._pinned is not None:
+            return real_build(opt_level)
+        col3._built_source, col3._built_options = source, options
         return bad, meta
     monkeypatch.setattr(col3, '_build_code_object', faulty_build)
-    with pytest.raises(hb.HipBackendError, match='confirms'):
-        col3.hip
+    assert col3.hip is not None
+    v3 = col3._build_verdict
+    assert v3['ok'] and v3['replaces'] == os.path.basename(bad), v3
+    assert v3['refused'][0][1]['opty_jac'] > 1e-9
+    assert col3._pinned is not None
+    import json
+    with open(tmp_path/'plans.json') as f:
+        plans = json.load(f)
+    (entry,) = plans.values()
+    assert entry['pinned']['label'] == v3['replacement']
+    free = problems.make_free(col3.num_free, variable_duration=True)
+    np.testing.assert_allclose(col3.generate_jacobian_function()(free),
+                               col.generate_jacobian_function()(free),
+                               rtol=1e-9, atol=1e-9)
+    col3.hip.close()
+    # ... which the next collocator of the same problem builds straight away
+    col4 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'third'), **kw)
+    pinned = col4._pinned_build()
+    assert pinned is not None and \
+        pinned[0].key() == col3._pinned[0].key()
+    # (2) a caller who fixed the geometry is told
+    col5 = opty_amd.ConstraintCollocator(
+        tmp_dir=str(tmp_path/'fifth'), emit_options=EmitOptions(), **kw)
+    monkeypatch.setattr(col5, '_build_code_object',
+                        lambda opt_level=None: (bad, meta))
+    with pytest.raises(hb.BuildRejected, match='disagree'):
+        col5.hip
+    # (3) nothing passes: refused
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', 'off')
+    col6 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'sixth'), **kw)
+    col6._build_code_object()
+    monkeypatch.setattr(hb, 'compile_module', lambda *a, **k: bad)
+    with pytest.raises(hb.BuildRejected, match='No neighbouring build'):
+        col6.hip
     monkeypatch.setenv('OPTY_CROSS_CHECK', 'off')
-    assert col3.hip is not None          # the documented opt-out
+    assert col6.hip is not None          # the documented opt-out
 
 
 def test_row_sorted_muscle_model_o1_twin_is_the_faulty_one():
-    """Round 4's find, kept as a regression test of the CHECK (not of the
-    compiler): the ``-O1`` build of the row-sorted module of the
+    """Round 4's first find, kept as a regression test of the CHECK (not of
+    the compiler): the ``-O1`` build of the row-sorted module of the
     muscle-driven leg has a Jacobian kernel that is 2.7 % off WITHOUT
-    spilling vector registers; the build in use is right and is confirmed --
-    by whichever twin agrees -- and matches the reference."""
+    spilling vector registers.  The build in use passes the referee; the
+    ``-O1`` twin -- if this compiler still miscompiles it -- does not."""
     import opty_amd
+    from opty_amd import hip_backend as hb
     kw = problems.build('one_legged_small')
     col = opty_amd.ConstraintCollocator(jacobian_layout='csr', **kw)
     col.hip
     verdict = col._build_verdict
-    assert verdict['ok'] and verdict['own'] < 1e-12, verdict
-    for twin in verdict['twins']:
-        # a twin that does not confirm the build disagrees with ITSELF
-        if min(twin['separate'], twin['fused']) > 1e-9:
-            assert twin['own'] > 1e-9, verdict
+    assert verdict['ok'] and verdict['worst'] < 1e-11, verdict
+    twin = hb.compile_module(col._built_source, col.tmp_dir, opt_level='-O1')
+    try:
+        col._verify_build(twin, col._kernel_meta, force=True)
+    except hb.BuildRejected as err:
+        assert err.verdict['errors']['opty_jac'] > 1e-9
+    else:
+        pytest.skip('this hipcc compiles the -O1 twin correctly')
+
+
+def test_biped_build_with_twenty_strips_is_refused():
+    """Round 4's second find: the spill-free ``-O2`` build of the
+    seven-segment biped with the printer's default 20 strips returns the
+    SAME wrong strip 17 from its separate and its fused Jacobian kernel
+    (220 entries off against the reference golden), and a twin from another
+    pipeline agrees with it -- a consensus of builds accepted it.  The
+    instruction tape does not; the collocator's own (pinned) build matches
+    the reference (``test_golden_full[biped_small]``)."""
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    from opty_amd.codegen.emit_hip import EmitOptions
+    kw = problems.build('biped_small')
+    col = opty_amd.ConstraintCollocator(
+        emit_options=EmitOptions(groups=20, fused_groups=20), **kw)
+    try:
+        col.hip
+    except hb.BuildRejected as err:
+        assert err.verdict['errors']['opty_jac'] > 1e-3
+        assert err.verdict['errors']['opty_conjac'] > 1e-3
+        assert err.verdict['errors']['opty_con'] < 1e-11
+    else:
+        pytest.skip('this hipcc compiles the 20-strip build correctly')
 
 
 @pytest.mark.gpu
