@@ -70,6 +70,13 @@ STRIP_ENTRIES = 100
 WORK_CUT_MAX_UNITS = 128
 WORK_CUT_MAX_SHARE = 3.0
 WORK_CUT_MAX_WEIGHT = 2.0
+#: ... and no strip whose estimated live temporaries (``_max_live``) exceed
+#: what 512 registers hold without spilling (measured: 238 builds clean, 274
+#: spills 30-60 registers)
+WORK_CUT_MAX_LIVE = 245
+#: what one more wave per block costs next to one weighted operation (slab
+#: fill, dispatch; measured on the biped: +1 % of the launch per strip)
+WORK_CUT_STRIP_OVERHEAD = 200
 STORE_WEIGHT = 6
 #: The fused kernel shares every block with the constraint waves and wants
 #: fewer, wider strips the larger the block: best counts 6-7 / 9 / 10-12 / 20
@@ -104,7 +111,7 @@ class EmitOptions(object):
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
-                 cut='even', con_attach=None, forget=0):
+                 cut=None, con_attach=None, forget=0, rotate=None):
         # 1: a strip's temporaries are dropped at every chunk boundary and
         # recomputed where needed again (bounded register pressure; the last
         # resort before a build that spills vector registers)
@@ -121,10 +128,19 @@ class EmitOptions(object):
         # block whose expensive entries share most of their sub-expressions
         # (the muscle-driven leg: 74 of 348 entries are not structural
         # zeros, every strip that touches rows 4-5 costs ~3400 of the
-        # block's 4460 weighted operations) is evaluated once instead of
-        # once per strip that happens to cross it
-        assert cut in ('even', 'work')
+        # block's 4460 weighted operations; the seven-segment biped: 24 even
+        # strips evaluate 29 600 weighted operations per node, 5 work-aware
+        # ones 12 500) is evaluated once instead of once per strip that
+        # happens to cross it.  None = automatic: the work-aware cut with the
+        # fewest strips the registers allow when the even cut's
+        # recomputation is what the block would wait for
+        # (_ModuleWriter._automatic_work_cut; only while ``groups`` is None)
+        assert cut in (None, 'even', 'work')
         self.cut = cut
+        # 1: the strip a block's first workgroup takes advances from block
+        # to block (_ModuleWriter.kernel); None = automatic (the unequal
+        # waves of a work-aware cut), 0 = every block in strip order
+        self.rotate = None if rotate is None else int(rotate)
         # 1: the waves of a block are dispatched longest first -- constraint
         # waves, then the Jacobian strips by descending evaluation work --
         # instead of in entry order (a launch of a few rounds ends when its
@@ -226,10 +242,11 @@ class EmitOptions(object):
                  if self.fused_groups is not None else '') +
                 ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
                 ('' if self.con_split == 'work' else ' con_split=count') +
-                ('' if self.cut == 'even' else ' cut=work') +
+                ('' if self.cut is None else ' cut=%s' % self.cut) +
                 ('' if self.con_attach is None
                  else ' con_attach=%d' % self.con_attach) +
                 (' forget=1' if self.forget else '') +
+                ('' if self.rotate is None else ' rotate=%d' % self.rotate) +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -477,6 +494,9 @@ class _ModuleWriter(object):
         self.inline_uni = bool(inline_uniform)
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
         self._auto = None           # (G_live, G) of group_ranges()
+        self._auto_work = None      # strips of the automatic work-aware cut
+        self._work_cut_objective = None
+        self._dense = {}            # unit range -> too many live values
         self._wcost = {}            # weighted work of entry ranges
         self._con_nt = False        # constraint stores of the kernel in print
 
@@ -590,13 +610,39 @@ class _ModuleWriter(object):
         wmax = max(1, int(-(-WORK_CUT_MAX_SHARE*nunits//S)))
         ends = [u*unit for u in range(nunits)] + [P]    # boundary k -> entry
         costs = {}
+        leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
+        dense = set()       # strips that do not fit the register file
         for a in range(nunits):
             for b in range(a + 1, min(nunits, a + wmax) + 1):
                 width = ends[b] - ends[a]
+                work = self._weighted_cost(ends[a], ends[b])
                 # (the small convex term breaks ties between cuts of a
                 # store-only region: even pieces, not slivers)
-                costs[a, b] = self._weighted_cost(ends[a], ends[b]) + \
+                costs[a, b] = work + \
                     STORE_WEIGHT*width + 0.25*STORE_WEIGHT*width*width/P
+                # a wave whose live temporaries exceed the register file
+                # spills (the muscle-driven leg: both dynamic rows in one
+                # strip, 274 live doubles, 30-60 spilled registers, slower
+                # than two strips of 220): such strips are not offered.  (A
+                # strip cannot keep more values alive than it computes.)
+                if work <= WORK_CUT_MAX_LIVE:
+                    continue
+                hit = self._dense.get((a, b))
+                if hit is None:
+                    hit = self._dense[a, b] = (
+                        (a, b - 1) in dense or (a + 1, b) in dense or
+                        _max_live(self.dag, [
+                            [self.p.jac_out[v % P] for v in range(c0, c1)]
+                            for c0, c1 in self._chunks(
+                                ends[a], self._virtual_end(ends[b]))],
+                            leaf) > WORK_CUT_MAX_LIVE)
+                if hit:
+                    dense.add((a, b))
+        if len(dense) < len(costs):
+            # (a single line that is too dense stays: it cannot be cut)
+            for ab in dense:
+                if ab[1] - ab[0] > 1:
+                    del costs[ab]
 
         def solve(bound):
             INF = float('inf')
@@ -607,8 +653,8 @@ class _ModuleWriter(object):
                 for b in range(s, nunits - (S - s) + 1):
                     for a in range(max(s - 1, b - wmax), b):
                         prev = best[s - 1].get(a)
-                        c = costs[a, b]
-                        if prev is None or c > bound:
+                        c = costs.get((a, b))
+                        if prev is None or c is None or c > bound:
                             continue
                         if prev + c < cur.get(b, INF):
                             cur[b], frm[b] = prev + c, a
@@ -636,10 +682,62 @@ class _ModuleWriter(object):
             if best_obj is None or obj < best_obj:
                 best_cuts, best_obj = cuts, obj
         if best_cuts is None:
-            b = [((g*nunits)//S)*unit for g in range(S)] + [P]
-            return [(b[g], b[g + 1]) for g in range(S)]
+            return None             # no S strips within the bounds
+        self._work_cut_objective = best_obj
         return [(ends[best_cuts[g]], ends[best_cuts[g + 1]])
                 for g in range(S)]
+
+    def _automatic_work_cut(self, even):
+        """The work-aware cut of a block whose EVEN cut (``even``: the
+        automatic strips) would make the launch wait for recomputed
+        arithmetic, or None.
+
+        Every strip evaluates what its entries need, so sub-expressions
+        shared by entries of different strips are evaluated once per strip.
+        For a store-bound block (the n-link pendulums: 17 x weighted
+        operations / bytes of the block well below 1) that hides behind the
+        stores and finer strips only help the store stream.  The rows of a
+        gait-like system share most of a long computation (contact forces,
+        musculotendon curves): the seven-segment biped's 24 even strips
+        evaluate 29 600 weighted operations per node where the block has 6
+        300, 13 of the 24 waves are long, and the launch takes 0.135 ms for
+        326 MB; cut where the work is (``_work_cut``) 4 waves carry the
+        arithmetic (12 500 operations in all) and ONE writes the 224 entries
+        of the kinematic rows: 0.073 ms (profiles/r04_work_cut.txt).  Fewer
+        strips are better as long as no wave outgrows the register file
+        (``WORK_CUT_MAX_LIVE``) or has to write too much besides: the count
+        is the one with the smallest ``sum + 2 max`` of the strips' costs
+        plus ``WORK_CUT_STRIP_OVERHEAD`` per wave (biped: 4 / 5 / 6 / 8 / 10
+        strips 0.078 / 0.073 / 0.075 / 0.078 / 0.080 ms fused).  Chosen when
+        the even cut's summed work per byte reaches ``ATTACH_MIN_INTENSITY``
+        and the work-aware cut saves at least a fifth of it."""
+        P = self.p.P
+        if not self.line_mode() or self.csr() or self.o.interleave or \
+                self.o.ablate is not None:
+            return None
+        nunits = P//16
+        if not 2 < nunits <= WORK_CUT_MAX_UNITS or len(even) < 3:
+            return None
+        work_even = sum(self._weighted_cost(e0, e1)
+                        for grp in even for e0, e1 in grp)
+        nbytes = 8.0*64*(P + self.p.M + len(self.p.rows))
+        if 17.0*work_even/nbytes < ATTACH_MIN_INTENSITY:
+            return None
+        first = max(2, (P + 255)//256)
+        best = None
+        for S in range(first, len(even) + 1):
+            cuts = self._work_cut(S, 16, nunits)
+            if cuts is None:
+                continue
+            obj = self._work_cut_objective + WORK_CUT_STRIP_OVERHEAD*S
+            if best is None or obj < best[0]:
+                best = (obj, cuts)
+            elif S > len(best[1]) + 2:
+                break               # more strips only add waves from here on
+        if best is None:
+            return None
+        work = sum(self._weighted_cost(e0, e1) for e0, e1 in best[1])
+        return best[1] if work <= 0.8*work_even else None
 
     def group_ranges(self, count=None):
         """Assigns the P entries of the block to G waves (``count`` of them,
@@ -674,7 +772,9 @@ class _ModuleWriter(object):
                 return [(b[g], b[g + 1]) for g in range(S)]
             if self.o.cut == 'work' and self.line_mode() and \
                     1 < S < nunits <= WORK_CUT_MAX_UNITS:
-                return self._work_cut(S, unit, nunits)
+                strips = self._work_cut(S, unit, nunits)
+                if strips is not None:
+                    return strips
             b = [((g*nunits)//S)*unit for g in range(S)] + [P]
             return [(b[g], b[g + 1]) for g in range(S)]
 
@@ -737,6 +837,13 @@ class _ModuleWriter(object):
             if self.line_mode():
                 fine = max(G, min(nunits, 32, -(-P//STRIP_ENTRIES)))
             self._auto = (G, fine)
+            if self.o.cut is None:
+                strips = self._automatic_work_cut(split(fine))
+                if strips is not None:
+                    self._auto_work = strips
+                    self._auto = (min(G, len(strips)), len(strips))
+        if self._auto_work is not None:
+            return [[rg] for rg in self._auto_work]
         return split(self._auto[1])
 
     def auto_groups(self):
@@ -1060,11 +1167,14 @@ class _ModuleWriter(object):
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
         if W is None:
             if G <= 4 and any(con_of_group) and \
+                    self.o.cut != 'work' and self._auto_work is None and \
                     any(e1 > e0 for grp in groups for e0, e1 in grp):
                 # the fused kernel of a small block: its few waves form ONE
                 # workgroup -- one slab fill, and the constraint wave rides in
                 # the Jacobian wave's LDS instead of reserving a ring tile it
-                # never uses in a workgroup of its own
+                # never uses in a workgroup of its own.  (Not the unequal
+                # waves of a work-aware cut: a workgroup keeps its CU's LDS
+                # until its longest wave is done.)
                 W = G
             else:
                 W = self._waves_per_workgroup(len(rows), ring_rows)
@@ -1104,10 +1214,23 @@ class _ModuleWriter(object):
                     '        if (threadIdx.x == 0) {']
             src += ['            ' + ln for ln in inst_lines]
             src += ['        }', '        return;', '    }']
+        rot = 'slot' if (first_group//W) % sets == 0 else \
+            '(slot + %d)' % ((first_group//W) % sets)
+        rotate = self.o.rotate
+        if rotate is None:
+            rotate = self.o.cut == 'work' or self._auto_work is not None
+        if rotate and sets > 1:
+            # Every block starts one strip further: the hardware hands
+            # consecutive workgroups of an XCD to consecutive CUs, so with a
+            # strip count that divides the CU count (4 strips, 32 CUs) every
+            # CU would see the same strip of every block -- a quarter of
+            # them the store-only one, the others only long waves (the
+            # biped's Jacobian kernel with 4 work-aware strips: 0.104 ms,
+            # with 5: 0.066 ms).
+            rot = '(%s + slot/%d)' % (rot, sets)
         src += [self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
                                       slab=len(rows)*TS, ring=ring_rows*TS,
-                                      rot='slot' if (first_group//W) % sets == 0 else
-                                      '(slot + %d)' % ((first_group//W) % sets))]
+                                      rot=rot)]
         src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
         if G == 1:
             src += ['    ' + ln for ln in bodies[0]]
@@ -1523,43 +1646,51 @@ def emit_module(prog, opts=None, node_blocks=None):
     fused_jac = groups
     if opts.groups is None:
         live, auto = w.auto_groups()
-        # the fused kernel carries the constraint waves as well
-        fused = max(live, min(auto, int(round(
-            FUSED_STRIPS_PER_SQRT_ENTRY*prog.P**0.5)))) if w.line_mode() \
-            else auto
-        dual = None
-        if node_blocks and int(node_blocks)*(fused + len(con_sets)) > \
-                RESIDENT_WAVES and not opts.con_rows_per_wave:
-            # at two waves per SIMD every wave has half the registers: the
-            # constraint rows are cut for that budget (one wave for the 22
-            # rows of the 10-link system needs 258 VGPRs, two spills under
-            # the 256 cap)
-            dual_sets = _constraint_waves(prog, w, opts, 0.5)
-            dual = _dual_occupancy_cut(prog, w, opts, live, len(dual_sets),
-                                       int(node_blocks))
-        if dual is not None:
-            opts, fused = dual
-            w = _ModuleWriter(prog, opts, inline)
-            groups = w.group_ranges(fused)
-            alone_sets = con_sets = dual_sets
-        elif node_blocks:
-            fit = _fit_one_round(auto, len(con_sets), int(node_blocks), live)
-            if fit != auto:
-                groups = w.group_ranges(fit)
-            fused = _fit_one_round(fused, len(con_sets), int(node_blocks),
-                                   live)
-        if opts.fused_groups is not None:
-            fused = opts.fused_groups
-        if fused != len(groups):
-            fused_jac = w.group_ranges(fused)
-        else:
+        if w._auto_work is not None and opts.fused_groups is None:
+            # the automatic work-aware cut (blocks that would wait for
+            # recomputed arithmetic) serves both Jacobian kernels as it is
             fused_jac = groups
+        else:
+            # the fused kernel carries the constraint waves as well
+            fused = max(live, min(auto, int(round(
+                FUSED_STRIPS_PER_SQRT_ENTRY*prog.P**0.5)))) if w.line_mode() \
+                else auto
+            dual = None
+            if node_blocks and int(node_blocks)*(fused + len(con_sets)) > \
+                    RESIDENT_WAVES and not opts.con_rows_per_wave:
+                # at two waves per SIMD every wave has half the registers:
+                # the constraint rows are cut for that budget (one wave for
+                # the 22 rows of the 10-link system needs 258 VGPRs, two
+                # spills under the 256 cap)
+                dual_sets = _constraint_waves(prog, w, opts, 0.5)
+                dual = _dual_occupancy_cut(prog, w, opts, live,
+                                           len(dual_sets), int(node_blocks))
+            if dual is not None:
+                opts, fused = dual
+                w = _ModuleWriter(prog, opts, inline)
+                groups = w.group_ranges(fused)
+                alone_sets = con_sets = dual_sets
+            elif node_blocks:
+                fit = _fit_one_round(auto, len(con_sets), int(node_blocks),
+                                     live)
+                if fit != auto:
+                    groups = w.group_ranges(fit)
+                fused = _fit_one_round(fused, len(con_sets), int(node_blocks),
+                                       live)
+            if opts.fused_groups is not None:
+                fused = opts.fused_groups
+            if fused != len(groups):
+                fused_jac = w.group_ranges(fused)
+            else:
+                fused_jac = groups
     elif opts.fused_groups is not None:
         fused_jac = w.group_ranges(opts.fused_groups)
     seeds = dict(jac=len(groups), fused=len(fused_jac),
                  con_waves=len(alone_sets), chunk=opts.chunk,
                  waves=opts.waves, occupancy=opts.occupancy,
                  line_mode=bool(w.line_mode()),
+                 cut='work' if (w._auto_work is not None or
+                                opts.cut == 'work') else 'even',
                  live=w.auto_groups()[0] if opts.groups is None else None)
     if opts.dear_first:
         def work(grp):

@@ -1082,7 +1082,7 @@ class ConstraintCollocator(object):
             self._uploaded_parameters = self._uploaded_trajectories = None
 
     def _descriptor(self, meta):
-        prog = self._program
+        prog = self._build_program()
         return dict(
             N=self.num_collocation_nodes, n=self.num_states, M=self.num_eom,
             m_known=self.num_known_input_trajectories,

@@ -816,6 +816,52 @@ def test_pinned_plans_are_built_exactly_as_recorded(tmp_path, monkeypatch):
     assert col3._pinned_build() is None
 
 
+def test_automatic_work_aware_cut():
+    """Blocks whose even cut would make the launch wait for recomputed
+    arithmetic -- the seven-segment biped: 24 even strips evaluate 4.7 times
+    the block's operations -- are cut where the work is, into the fewest
+    strips the register file allows; both Jacobian kernels use that cut.
+    Store-bound blocks keep their even strips; an explicit strip count is an
+    even cut as before."""
+    from opty_amd.codegen import emit_hip as eh
+    col = ConstraintCollocator(**problems.build('biped_small'))
+    prog = col._build_program()
+    src, meta = emit_module(prog, EmitOptions(), node_blocks=782)
+    geo = meta['geometry']
+    assert geo['cut'] == 'work' and geo['jac'] == geo['fused'] <= 6
+    assert meta['groups'] == meta['fused_groups']
+    strips = [tuple(rg) for grp in meta['groups'] for rg in grp]
+    assert strips[0][0] == 0 and strips[-1][1] == prog.P
+    assert all(a[1] == b[0] and a[1] % 16 == 0
+               for a, b in zip(strips, strips[1:]))
+    w = eh._ModuleWriter(prog, EmitOptions())
+    leaf = lambda i: w._is_vec_input(i) or w._uniform_leaf(i)
+    work = sum(w._weighted_cost(*rg) for rg in strips)
+    for e0, e1 in strips:
+        chunks = [[prog.jac_out[v % prog.P] for v in range(a, b)]
+                  for a, b in w._chunks(e0, w._virtual_end(e1))]
+        assert eh._max_live(prog.dag, chunks, leaf) <= eh.WORK_CUT_MAX_LIVE
+    _, even = emit_module(prog, EmitOptions(cut='even'), node_blocks=782)
+    assert even['geometry']['cut'] == 'even'
+    work_even = sum(w._weighted_cost(*rg) for grp in even['groups']
+                    for rg in grp)
+    assert work <= 0.8*work_even
+    # no strip count admits the bounds: None, and the explicit option falls
+    # back on even strips
+    assert w._work_cut(2, 16, prog.P//16) is None
+    _, two = emit_module(prog, EmitOptions(cut='work', groups=2,
+                                           fused_groups=2), node_blocks=782)
+    assert [rg for grp in two['groups'] for rg in grp] == \
+        [[0, 384], [384, prog.P]]
+    # store-bound: even strips
+    for name in ('config3_10link_small', 'pend3_link_midpoint_small',
+                 'one_legged_small'):
+        col = ConstraintCollocator(**problems.build(name))
+        _, m = emit_module(col._build_program(), EmitOptions(),
+                           node_blocks=782)
+        assert m['geometry']['cut'] == 'even', name
+
+
 def test_spill_loop_falls_back_on_recomputation_per_chunk():
     """The muscle-driven leg under the midpoint rule: every cut of its block
     spills 24+ vector registers (with or without the constraint rows in the

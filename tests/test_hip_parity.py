@@ -944,7 +944,6 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
     hsaco = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
     assert any(os.path.exists(os.path.join(tmp_path, f + '.crosscheck.json'))
                for f in hsaco)
-    hip.close()
     # same geometry, other values
     eom = kw['equations_of_motion']
     wrong = opty_amd.ConstraintCollocator(
@@ -980,6 +979,7 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
                                col.generate_jacobian_function()(free),
                                rtol=1e-9, atol=1e-9)
     col3.hip.close()
+    hip.close()
     # ... which the next collocator of the same problem builds straight away
     col4 = opty_amd.ConstraintCollocator(tmp_dir=str(tmp_path/'third'), **kw)
     pinned = col4._pinned_build()

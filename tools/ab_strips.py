@@ -28,7 +28,7 @@ def main():
     workload = 'config3_10link'
     if args and '=' not in args[0] and args[0] not in ('default', 'auto'):
         workload = args.pop(0)
-    dev = torch.device('cuda:0')
+    dev = torch.device('cuda:0') if torch.cuda.is_available() else None
     factory, fkw = problems.CONFIGS[workload]
     if os.environ.get('OPTY_TUNE_NODES'):
         fkw = dict(fkw, num_nodes=int(os.environ['OPTY_TUNE_NODES']))
@@ -42,8 +42,19 @@ def main():
         opts = None if spec == 'auto' else (
             EmitOptions() if spec == 'default' else parse(spec))
         col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
-        col.hip.use_torch_stream()
+        if not torch.cuda.is_available():
+            hsaco, meta = col._build_code_object()      # prebuild only
+            print(spec, hb.vgpr_spills(hsaco), flush=True)
+            continue
+        try:
+            col.hip.use_torch_stream()
+        except hb.BuildRejected as err:
+            print('%-28s REFUSED by the verification: %s'
+                  % (spec, err.verdict['errors']), flush=True)
+            continue
         cols.append((spec, col))
+    if not cols:
+        return
     col = cols[0][1]
     free = torch.from_numpy(problems.make_free(
         col.num_free, variable_duration=col._variable_duration)).to(dev)
