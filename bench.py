@@ -840,7 +840,15 @@ def main():
                           dtype=torch.float64)
         if world > 1:
             st = st.to(dev) if not oversub else st
-            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            try:
+                dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            except RuntimeError:
+                # a peer that the watchdog has ended already (its connection
+                # is gone): same ending here, not a traceback
+                if strong and not args.no_extras:
+                    watchdog.cancel()
+                    give_up()
+                raise
             st = st.cpu()
         verify = {
             'ok': bool(st[1].item() == 0 and st[0].item() <= 1e-10),

@@ -132,6 +132,10 @@ def candidates(prog, node_blocks):
     _, meta = emit_module(prog, EmitOptions(), node_blocks=node_blocks)
     g = meta['geometry']
     seed = dict(groups=g['jac'], fused_groups=g['fused'])
+    if g.get('cut') == 'work':
+        # the printer chose the work-aware cut (emit_hip._automatic_work_cut):
+        # its neighbours are work-aware cuts with other strip counts
+        seed['cut'] = 'work'
     if g['chunk'] != 32 or g['occupancy']:
         # the small-launch geometry (two waves per SIMD) came with its own
         # chunk / workgroup width: keep them with the seed
