@@ -33,6 +33,7 @@ Jacobian has thousands of temporaries.  The printer therefore
 """
 
 import hashlib
+import os
 
 from . import ir
 
@@ -73,7 +74,7 @@ WORK_CUT_MAX_WEIGHT = 2.0
 #: ... and no strip whose estimated live temporaries (``_max_live``) exceed
 #: what 512 registers hold without spilling (measured: 238 builds clean, 274
 #: spills 30-60 registers)
-WORK_CUT_MAX_LIVE = 245
+WORK_CUT_MAX_LIVE = int(os.environ.get('OPTY_WORK_CUT_MAX_LIVE', 245))
 #: what one more wave per block costs next to one weighted operation (slab
 #: fill, dispatch; measured on the biped: +1 % of the launch per strip)
 WORK_CUT_STRIP_OVERHEAD = 200
