@@ -724,7 +724,7 @@ class ConstraintCollocator(object):
         import os
         from concurrent.futures import ThreadPoolExecutor
         from . import launch_plan
-        base = self._built_options
+        base = self._built_options or self._printer_options()
         geo = meta['geometry']
         cands = []
         if geo['line_mode'] or self._jacobian_layout == 'csr':
@@ -849,8 +849,14 @@ class ConstraintCollocator(object):
             pass
         logger.info('kernels %s are at the register limit: checking the '
                     'build against the instruction tape', hot)
-        con, jac, con2, jac2 = self._evaluate_build(meta, hsaco)
-        rcon, rjac, con_row, jac_row = self._reference_values()
+        # seeded inputs from (-1, 1); equations that are not finite there
+        # (square roots, logarithms of states) are tried on narrower positive
+        # ranges -- what stays non-finite must be non-finite in the build too
+        for span in self._VERIFY_SPANS:
+            rcon, rjac, con_row, jac_row = self._reference_values(span=span)
+            if np.isfinite(rcon).all() and np.isfinite(rjac).all():
+                break
+        con, jac, con2, jac2 = self._evaluate_build(meta, hsaco, span=span)
         errors = {
             'opty_con': self._row_error(con, rcon, con_row),
             'opty_jac': self._row_error(jac, rjac, jac_row),
@@ -858,7 +864,8 @@ class ConstraintCollocator(object):
                                self._row_error(jac2, rjac, jac_row))}
         worst = max(errors.values())
         verdict = dict(ok=bool(worst <= self._VERIFY_RTOL), referee='tape',
-                       worst=worst, errors=errors, nodes=int(
+                       worst=worst, errors=errors, span=list(span),
+                       nodes=int(
                            min(self.num_collocation_nodes,
                                self._VERIFY_NODES)),
                        kernels={k: list(v) for k, v in hot.items()})
@@ -879,41 +886,49 @@ class ConstraintCollocator(object):
             pass
         return verdict
 
+    _VERIFY_SPANS = ((-1.0, 1.0), (0.1, 0.9), (0.45, 0.55))
+
     @staticmethod
     def _row_error(got, want, row):
         """Largest difference between two vectors relative to the largest
-        reference value of the entry's own equation (inf for non-finite
-        values); ``row[k]`` = equation of entry ``k``."""
+        (finite) reference value of the entry's own equation; ``row[k]`` =
+        equation of entry ``k``.  Entries that are NaN in both, or the same
+        infinity in both, agree; any other non-finite difference is inf."""
         if not want.size:
             return 0.0
-        d = np.abs(got - want)
+        with np.errstate(all='ignore'):
+            same = (np.isnan(got) & np.isnan(want)) | (
+                np.isinf(got) & np.isinf(want) & (got == want))
+            d = np.where(same, 0.0, np.abs(got - want))
         if not np.isfinite(d).all():
             return float('inf')
         scale = np.zeros(int(row.max()) + 1)
-        np.maximum.at(scale, row, np.abs(want))
+        np.maximum.at(scale, row, np.where(np.isfinite(want),
+                                           np.abs(want), 0.0))
         scale = np.maximum(scale, 1e-300)
         return float((d/scale[row]).max())
 
-    def _verification_inputs(self, seed=7):
+    def _verification_inputs(self, seed=7, span=(-1.0, 1.0)):
         """``(N, free)`` of the small problem the verification evaluates:
-        the first ``_VERIFY_NODES`` nodes, seeded values."""
+        the first ``_VERIFY_NODES`` nodes, seeded values from ``span``."""
         N = min(self.num_collocation_nodes, self._VERIFY_NODES)
         n, q = self.num_states, self.num_unknown_input_trajectories
         rng = np.random.default_rng(seed)
-        free = rng.uniform(-1.0, 1.0, (n + q)*N + self.num_unknown_parameters
+        free = rng.uniform(span[0], span[1],
+                           (n + q)*N + self.num_unknown_parameters
                            + int(self._variable_duration))
         if self._variable_duration:
             free[-1] = 0.01
         return N, free
 
-    def _reference_values(self, seed=7):
+    def _reference_values(self, seed=7, span=(-1.0, 1.0)):
         """Constraints and Jacobian values of the verification problem from
         the instruction tape run on the device (``opty_hip_tape_run``), in
         the layouts the kernels write: ``(con, jac, con_row, jac_row)``,
         ``*_row[k]`` = equation of entry ``k``."""
         from .codegen.tape import Tape
         prog = self._build_program()
-        N, free = self._verification_inputs(seed)
+        N, free = self._verification_inputs(seed, span)
         ncn = N - 1
         n, q = prog.n, prog.q
         known = self._known_trajectory_array(np.ones(self.num_free))[:, :N] \
@@ -959,11 +974,11 @@ class ConstraintCollocator(object):
             jac_row = np.tile(ent_row, ncn)
         return con, jac, con_row, jac_row
 
-    def _evaluate_build(self, meta, hsaco, seed=7):
+    def _evaluate_build(self, meta, hsaco, seed=7, span=(-1.0, 1.0)):
         """``[con, jac, fused con, fused jac]`` of one code object of this
         problem's module on the first ``_VERIFY_NODES`` nodes: separate and
         fused launches, host buffers, no instance tails (scalar code)."""
-        N, free = self._verification_inputs(seed)
+        N, free = self._verification_inputs(seed, span)
         desc = dict(self._descriptor(meta), N=N, num_inst=0, nnz_inst=0,
                     num_inst_atoms=0, inst_folded=0)
         if self._jacobian_layout == 'varying_first':

@@ -125,3 +125,36 @@ def test_tape_run_rejects_a_malformed_tape():
         bad.code[3, column] = value
         with pytest.raises(hb.HipBackendError, match='instruction 3'):
             hb.tape_run(bad, vals.copy())
+
+
+def test_row_error_treats_shared_non_finite_values_as_agreement():
+    from opty_amd import ConstraintCollocator
+    err = ConstraintCollocator._row_error
+    row = np.array([0, 0, 1, 1])
+    want = np.array([1.0, np.nan, np.inf, 2.0])
+    assert err(want.copy(), want, row) == 0.0
+    assert err(np.array([1.0, np.nan, np.inf, 2.0 + 2e-9]), want, row) == \
+        pytest.approx(1e-9)
+    assert err(np.array([1.0, 0.0, np.inf, 2.0]), want, row) == np.inf
+    assert err(np.array([1.0, np.nan, -np.inf, 2.0]), want, row) == np.inf
+
+
+@pytest.mark.gpu
+def test_verification_moves_to_positive_inputs_when_needed(monkeypatch,
+                                                           tmp_path):
+    """Equations that are not finite on the seeded inputs from (-1, 1)
+    (square roots / logarithms of states) are verified on a positive
+    range."""
+    import sympy as sm
+    import sympy.physics.mechanics as me
+    import opty_amd
+    monkeypatch.setenv('OPTY_CROSS_CHECK', 'all')
+    t = me.dynamicsymbols._t
+    x, v, f = me.dynamicsymbols('x v f')
+    eom = sm.Matrix([x.diff(t) - v,
+                     v.diff(t) + sm.sqrt(x) + sm.log(x)*v - f])
+    col = opty_amd.ConstraintCollocator(eom, (x, v), 50, 0.01,
+                                        tmp_dir=str(tmp_path))
+    assert col.hip is not None
+    verdict = col._build_verdict
+    assert verdict['ok'] and verdict['span'] == [0.1, 0.9], verdict

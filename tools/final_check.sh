@@ -21,7 +21,7 @@ d = json.loads([l for l in open("gpurun_out/${tag}_bench.json") if l.startswith(
 c = d["config"]
 print(d["value"], d["roofline"]["frac"], c["kernel_ms"], c["verify"]["ok"])
 print(c["host_path_ms"])
-print({k: (round(v["fused_hbm_frac"], 3), v.get("shard_1of8", {}).get("speedup_vs_whole"),
-           v.get("host_path_us")) for k, v in c["other_configs"].items()})
+print({k: (round(v.get("fused_hbm_frac", -1), 3), v.get("shard_1of8", {}).get("speedup_vs_whole"),
+           v.get("host_path_us"), v.get("error")) for k, v in c["other_configs"].items()})
 print(d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"])
 PY
