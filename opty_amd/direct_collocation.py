@@ -132,6 +132,7 @@ class ConstraintCollocator(object):
         self._pinned = None         # (EmitOptions, hipcc switches), see
         #                             _verified_alternative
         self._built_options = None
+        self._tape = None           # instruction tape of the program's DAG
 
         self._sort_parameters()
         self._sort_trajectories()
@@ -926,13 +927,24 @@ class ConstraintCollocator(object):
         the instruction tape run on the device (``opty_hip_tape_run``), in
         the layouts the kernels write: ``(con, jac, con_row, jac_row)``,
         ``*_row[k]`` = equation of entry ``k``."""
-        from .codegen.tape import Tape
-        prog = self._build_program()
         N, free = self._verification_inputs(seed, span)
-        ncn = N - 1
-        n, q = prog.n, prog.q
         known = self._known_trajectory_array(np.ones(self.num_free))[:, :N] \
             if self.num_known_input_trajectories else None
+        return self._tape_values(free, N, 0, N - 1, known)
+
+    def _tape_values(self, free, N, a, b, known):
+        """Constraints and Jacobian values of the constraint nodes ``[a, b)``
+        of an ``N``-node problem with free vector ``free`` (known
+        trajectories ``known``, ``(m_known, N)``), evaluated from the
+        expression DAG by the instruction tape on the device
+        (``opty_hip_tape_run``): ``(con, jac, con_row, jac_row)`` in the
+        layouts the kernels write for that node range -- ``con[j*(b-a) +
+        i]``; ``jac[i*P + e]``, or ``jac[S_j*(b-a) + i*L_j + pos]`` for the
+        row-sorted layout -- with ``*_row[k]`` = equation of entry ``k``."""
+        from .codegen.tape import Tape
+        prog = self._build_program()
+        ncn = b - a
+        n, q = prog.n, prog.q
         tail = free[(n + q)*N:]
         kpar = [float(self.known_parameter_map[p])
                 for p in self.known_parameters]
@@ -942,7 +954,7 @@ class ConstraintCollocator(object):
                 src, k = prog.rows[idx]
                 row = free[k*N:(k + 1)*N] if src == 'free' else known[k]
                 off = prog.cur_offset if kind == 'cur' else prog.adj_offset
-                return row[off:off + ncn]
+                return row[a + off:b + off]
             if kind == 'par':
                 src, k = prog.pars[idx]
                 return kpar[k] if src == 'known' else tail[k]
@@ -950,8 +962,10 @@ class ConstraintCollocator(object):
             return self.node_time_interval if prog.h[0] == 'fixed' \
                 else tail[prog.h[1]]
 
-        roots = list(prog.con_out) + list(prog.jac_out)
-        tape = Tape(prog.dag, roots)
+        if self._tape is None:
+            self._tape = Tape(prog.dag,
+                              list(prog.con_out) + list(prog.jac_out))
+        tape = self._tape
         vals = hb.tape_run(tape, tape.table(ncn, inputs), self._device)
         M, P = prog.M, prog.P
         con = np.concatenate([vals[tape.slot[r]] for r in prog.con_out]) \
@@ -1023,24 +1037,32 @@ class ConstraintCollocator(object):
             self._emit_options = None
         return entry
 
-    def cross_check(self, free=None, window=4096, opt_level='-O1'):
-        """Evaluates this problem's kernels twice -- the build in use and a
-        build of the SAME generated module that went through another compiler
-        pipeline (``hipcc -O1``) -- on the same ``free`` (default: seeded
-        random values) and returns the largest disagreement of constraints
-        and Jacobian values over the first and last ``window`` constraint
-        nodes, relative to the largest value of each vector (rounding level,
-        ~1e-15, when both builds are right).
+    def cross_check(self, free=None, window=4096, opt_level='-O1',
+                    referee='tape'):
+        """Evaluates this problem's kernels on ``free`` (default: seeded
+        random values) over the first and last ``window`` constraint nodes
+        and returns their largest disagreement with a referee:
 
-        A disagreement means that ONE of the two builds is faulty, not
-        which: round 4 met ``-O1`` kernels that were the wrong ones
-        (DESIGN.md section 4.1).  The automatic check every build at the
-        register limit goes through before its handle exists
-        (:meth:`_verify_build`: the build's separate and fused kernels
-        against each other, then against twins until one confirms them)
-        decides that; this method is the same comparison on demand, over
-        larger node windows and with the caller's ``free``.  Needs
-        ``torch``."""
+        * ``referee='tape'`` (node-major layouts): the expression DAG itself,
+          executed as an instruction tape on the device
+          (``opty_hip_tape_run``) -- the error of the
+          build in use, each entry relative to the largest value of its
+          equation in the window (rounding level, ~1e-15, for a right build);
+          the window is capped so that the tape's value table stays below
+          512 MB;
+        * ``referee='-O1'`` (and the row-sorted layout): a build of the SAME
+          generated module that went through another compiler pipeline
+          (``hipcc`` with ``opt_level``), relative to the largest value of
+          each vector.  A disagreement then means that ONE of the two builds
+          is faulty, not which: round 4 met ``-O1`` kernels that were the
+          wrong ones.
+
+        Builds at the register limit go through the tape check on 131 seeded
+        nodes before their handle exists (:meth:`_verify_build`); this is the
+        same comparison on demand, over larger node windows and with the
+        caller's ``free``.  Needs ``torch``."""
+        if referee == 'tape' and self._jacobian_layout == 'coo':
+            return self._cross_check_tape(free, window)
         import torch
         hip = self._ensure_hip()
         meta = self._kernel_meta
@@ -1095,6 +1117,43 @@ class ConstraintCollocator(object):
             twin.close()
             # the upload cache belongs to the handle in use
             self._uploaded_parameters = self._uploaded_trajectories = None
+
+    def _cross_check_tape(self, free, window):
+        import torch
+        hip = self._ensure_hip()
+        if free is None:
+            free = np.random.default_rng(7).uniform(-1.0, 1.0, self.num_free)
+            if self._variable_duration:
+                free[-1] = 0.01
+        free = self._host_free(free)
+        self._sync_known(hip, free)
+        prog = self._build_program()
+        N = self.num_collocation_nodes
+        ncn = N - 1
+        known = self._known_trajectory_array(free) \
+            if self.num_known_input_trajectories else None
+        from .codegen.tape import Tape
+        if self._tape is None:
+            self._tape = Tape(prog.dag,
+                              list(prog.con_out) + list(prog.jac_out))
+        cap = max(64, (512 << 20)//(8*max(1, self._tape.nslots)))
+        w = max(1, min(int(window), ncn, cap))
+        dev = torch.device('cuda', self._device)
+        d_free = torch.from_numpy(free).to(dev)
+        P, M = prog.P, self.num_eom
+        worst = 0.0
+        for a, b in sorted({(0, w), (ncn - w, ncn)}):
+            con = torch.empty((M, b - a), dtype=torch.float64, device=dev)
+            jac = torch.empty((b - a)*P, dtype=torch.float64, device=dev)
+            hip.eval_shard(hb.EVAL_FUSED, d_free, con, b - a, jac, a, b)
+            hip.synchronize()
+            rcon, rjac, con_row, jac_row = self._tape_values(free, N, a, b,
+                                                             known)
+            worst = max(worst,
+                        self._row_error(con.cpu().numpy().ravel(), rcon,
+                                        con_row),
+                        self._row_error(jac.cpu().numpy(), rjac, jac_row))
+        return worst
 
     def _descriptor(self, meta):
         prog = self._build_program()

@@ -1054,9 +1054,11 @@ def test_biped_build_with_twenty_strips_is_refused():
     ('config3_10link_small', 'coo'), ('elementary_mid_small', 'coo'),
     ('config5_standin_24link_small', 'csr')])
 def test_cross_check_against_another_compiler_pipeline(name, layout):
-    """``ConstraintCollocator.cross_check``: the build in use and an ``-O1``
-    twin of the same generated module agree to rounding on the first and last
-    nodes, for the caller's ``free`` or seeded random values."""
+    """``ConstraintCollocator.cross_check``: the build in use agrees to
+    rounding with the expression DAG run as an instruction tape on the device
+    (node-major layouts) and with an ``-O1`` twin of the same generated
+    module, on the first and last nodes, for the caller's ``free`` or seeded
+    random values."""
     import opty_amd
     col = opty_amd.ConstraintCollocator(jacobian_layout=layout,
                                         **problems.build(name))
@@ -1064,6 +1066,9 @@ def test_cross_check_against_another_compiler_pipeline(name, layout):
     free = problems.make_free(col.num_free, seed=3,
                               variable_duration=col._variable_duration)
     assert col.cross_check(free) <= 1e-12
+    # (node-major layouts are held to the instruction tape by default; the
+    # twin from another pipeline on request)
+    assert col.cross_check(free, window=33, referee='-O1') <= 1e-12
     # the collocator goes on working with its own build
     z = col.generate_constraint_function()(free)
     assert np.isfinite(z).all()
