@@ -1,6 +1,6 @@
 """Developer tool (GPU): where a build's Jacobian differs from the reference
 golden -- per kernel (separate / fused), per strip, per (equation, column).
-Usage: dbg_biped.py <golden name> [-O1] [key=value printer options ...]"""
+Usage: dbg_golden.py <golden name> [-O1] [key=value printer options ...]"""
 import os
 import sys
 sys.path.insert(0, '.')
