@@ -728,12 +728,15 @@ class ConstraintCollocator(object):
         base = self._built_options or self._printer_options()
         geo = meta['geometry']
         cands = []
+        # (an explicit strip count is an even cut unless the work-aware one
+        # is asked for: the neighbours of a work-aware cut are work-aware)
+        keep = dict(cut='work') if geo.get('cut') == 'work' else {}
         if geo['line_mode'] or self._jacobian_layout == 'csr':
             for d in (2, 4, 1, 6, 8, 12, -2, -4):
                 if min(geo['jac'], geo['fused']) + d >= 1:
                     cands.append(('strips%+d' % d, dict(
-                        groups=geo['jac'] + d, fused_groups=geo['fused'] + d),
-                        {}))
+                        keep, groups=geo['jac'] + d,
+                        fused_groups=geo['fused'] + d), {}))
         if not base.fast_trig:
             cands.append(('fast_trig', dict(fast_trig=1), {}))
         if geo['line_mode'] and base.chunk == 32:
