@@ -626,6 +626,9 @@ class ConstraintCollocator(object):
                 # _attach_constraint_rows) get their registers back
                 trial.con_attach = 0
             if d:
+                if geo.get('cut') == 'work':
+                    trial.cut = 'work'      # (an explicit count is an even
+                    #                          cut otherwise)
                 trial.groups = geo['jac'] + (d if 'opty_jac' in best[2]
                                              else 0)
                 trial.fused_groups = geo['fused'] + (
