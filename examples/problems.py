@@ -624,6 +624,8 @@ CONFIGS = {
     # a real muscle-driven DAE with a reference golden (config-5 class)
     # seven-segment planar biped: the structure of the gait model of config 5
     'biped_small': (planar_biped, {'num_nodes': 9}),
+    'biped_mid_small': (planar_biped, {'num_nodes': 9,
+                                       'method': 'midpoint'}),
     'config5_biped': (planar_biped, {}),
     'one_legged_small': (gallery_problem, {'num_nodes': 43}),
     'config5_one_legged': (gallery_problem, {'num_nodes': 50000}),

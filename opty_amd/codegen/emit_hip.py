@@ -112,7 +112,8 @@ class EmitOptions(object):
                  interleave=0, pad=0, occupancy=0, con_nt=None, fast_trig=0,
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
-                 cut=None, con_attach=None, forget=0, rotate=None):
+                 cut=None, con_attach=None, forget=0, rotate=None,
+                 work_live=None):
         # 1: a strip's temporaries are dropped at every chunk boundary and
         # recomputed where needed again (bounded register pressure; the last
         # resort before a build that spills vector registers)
@@ -138,6 +139,10 @@ class EmitOptions(object):
         # (_ModuleWriter._automatic_work_cut; only while ``groups`` is None)
         assert cut in (None, 'even', 'work')
         self.cut = cut
+        # live temporaries a strip of a work-aware cut may have (None:
+        # WORK_CUT_MAX_LIVE); what the spill-free builder lowers when such a
+        # cut spills -- more strips would only split the store-only part
+        self.work_live = None if work_live is None else int(work_live)
         # 1: the strip a block's first workgroup takes advances from block
         # to block (_ModuleWriter.kernel); None = automatic (the unequal
         # waves of a work-aware cut), 0 = every block in strip order
@@ -248,6 +253,8 @@ class EmitOptions(object):
                  else ' con_attach=%d' % self.con_attach) +
                 (' forget=1' if self.forget else '') +
                 ('' if self.rotate is None else ' rotate=%d' % self.rotate) +
+                ('' if self.work_live is None
+                 else ' work_live=%d' % self.work_live) +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -497,7 +504,7 @@ class _ModuleWriter(object):
         self._auto = None           # (G_live, G) of group_ranges()
         self._auto_work = None      # strips of the automatic work-aware cut
         self._work_cut_objective = None
-        self._dense = {}            # unit range -> too many live values
+        self._dense = {}            # unit range -> estimated live values
         self._wcost = {}            # weighted work of entry ranges
         self._con_nt = False        # constraint stores of the kernel in print
 
@@ -611,6 +618,7 @@ class _ModuleWriter(object):
         wmax = max(1, int(-(-WORK_CUT_MAX_SHARE*nunits//S)))
         ends = [u*unit for u in range(nunits)] + [P]    # boundary k -> entry
         costs = {}
+        limit = self.o.work_live or WORK_CUT_MAX_LIVE
         leaf = lambda i: self._is_vec_input(i) or self._uniform_leaf(i)
         dense = set()       # strips that do not fit the register file
         for a in range(nunits):
@@ -626,18 +634,18 @@ class _ModuleWriter(object):
                 # strip, 274 live doubles, 30-60 spilled registers, slower
                 # than two strips of 220): such strips are not offered.  (A
                 # strip cannot keep more values alive than it computes.)
-                if work <= WORK_CUT_MAX_LIVE:
+                if work <= limit:
                     continue
-                hit = self._dense.get((a, b))
-                if hit is None:
-                    hit = self._dense[a, b] = (
-                        (a, b - 1) in dense or (a + 1, b) in dense or
-                        _max_live(self.dag, [
-                            [self.p.jac_out[v % P] for v in range(c0, c1)]
-                            for c0, c1 in self._chunks(
-                                ends[a], self._virtual_end(ends[b]))],
-                            leaf) > WORK_CUT_MAX_LIVE)
-                if hit:
+                if (a, b - 1) in dense or (a + 1, b) in dense:
+                    dense.add((a, b))
+                    continue
+                live = self._dense.get((a, b))
+                if live is None:
+                    live = self._dense[a, b] = _max_live(self.dag, [
+                        [self.p.jac_out[v % P] for v in range(c0, c1)]
+                        for c0, c1 in self._chunks(
+                            ends[a], self._virtual_end(ends[b]))], leaf)
+                if live > limit:
                     dense.add((a, b))
         if len(dense) < len(costs):
             # (a single line that is too dense stays: it cannot be cut)
@@ -711,7 +719,7 @@ class _ModuleWriter(object):
         plus ``WORK_CUT_STRIP_OVERHEAD`` per wave (biped: 4 / 5 / 6 / 8 / 10
         strips 0.078 / 0.073 / 0.075 / 0.078 / 0.080 ms fused).  Chosen when
         the even cut's summed work per byte reaches ``ATTACH_MIN_INTENSITY``
-        and the work-aware cut saves at least a fifth of it."""
+        and the work-aware cut saves at least a tenth of it."""
         P = self.p.P
         if not self.line_mode() or self.csr() or self.o.interleave or \
                 self.o.ablate is not None:
@@ -738,7 +746,7 @@ class _ModuleWriter(object):
         if best is None:
             return None
         work = sum(self._weighted_cost(e0, e1) for e0, e1 in best[1])
-        return best[1] if work <= 0.8*work_even else None
+        return best[1] if work <= 0.9*work_even else None
 
     def group_ranges(self, count=None):
         """Assigns the P entries of the block to G waves (``count`` of them,

@@ -625,10 +625,13 @@ class ConstraintCollocator(object):
                 # waves they rode in (arithmetic-bound blocks, emit_hip.
                 # _attach_constraint_rows) get their registers back
                 trial.con_attach = 0
-            if d:
-                if geo.get('cut') == 'work':
-                    trial.cut = 'work'      # (an explicit count is an even
-                    #                          cut otherwise)
+            if d and geo.get('cut') == 'work':
+                # more strips would only split the store-only part of a
+                # work-aware cut: its arithmetic strips get a smaller
+                # register budget instead (the strip count follows)
+                from .codegen.emit_hip import WORK_CUT_MAX_LIVE
+                trial.work_live = max(40, WORK_CUT_MAX_LIVE - 12*d)
+            elif d:
                 trial.groups = geo['jac'] + (d if 'opty_jac' in best[2]
                                              else 0)
                 trial.fused_groups = geo['fused'] + (

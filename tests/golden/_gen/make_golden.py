@@ -52,7 +52,7 @@ SMALL = ['config1_vyasarayani', 'config2_pendulum_small',
          'piecewise_be_small', 'piecewise_mid_small',
          'states_only_mid_small', 'gaitlike_3link_be_small',
          'gaitlike_3link_mid_small', 'config5_gaitlike_24link_small',
-         'one_legged_small', 'biped_small']
+         'one_legged_small', 'biped_small', 'biped_mid_small']
 LARGE = {'config2_pendulum': 499, 'config3_10link': 4999,
          'config5_standin_24link': 4999, 'config5_gaitlike_24link': 4999,
          'config5_one_legged': 4999, 'config5_biped': 4999}
