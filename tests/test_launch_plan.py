@@ -93,5 +93,10 @@ def test_the_tracked_plan_file_is_well_formed():
         sha, b, arch = key.split(':')
         assert arch == 'gfx950' and 0 <= int(b) <= 12 and len(sha) == 20
         EmitOptions(**entry['options'])
+        if entry.get('pinned') is not None:
+            # a build that replaced one the verification refused
+            assert set(entry) >= {'options', 'pinned', 'refused', 'nodes'}
+            assert set(entry['pinned']) >= {'label', 'replaces'}
+            continue
         assert set(entry) >= {'options', 'seed', 'measured_ms', 'nodes',
                               'device'}
