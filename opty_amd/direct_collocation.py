@@ -857,15 +857,19 @@ class ConstraintCollocator(object):
         return self._build_code_object()
 
     #: nodes the automatic check below evaluates (``OPTY_CROSS_CHECK=off``
-    #: disables it, ``=all`` extends it to every build)
+    #: disables it, ``=hot`` restricts it to builds at the register limit)
     _VERIFY_NODES = 131
     _VERIFY_RTOL = 1e-9
 
     def _verify_build(self, hsaco, meta, force=False):
-        """Holds a build whose kernels sit at the edge of the register file
+        """Holds a build to the expression DAG itself before the handle is
+        handed out; raises :class:`hip_backend.BuildRejected` when a kernel
+        disagrees.  Every build goes through it once (a fraction of a second
+        next to the seconds of its compilation; the verdict is cached next to
+        the code object); ``OPTY_CROSS_CHECK=hot`` restricts it to the builds
+        that have actually failed -- kernels at the edge of the register file
         (``hip_backend.high_pressure_kernels``: >= 480 VGPRs or spilled
-        SGPRs) to the expression DAG itself before the handle is handed out;
-        raises :class:`hip_backend.BuildRejected` when a kernel disagrees.
+        SGPRs) --, ``=off`` disables it.
 
         Why: hipcc 7.2 has produced code objects of exactly such kernels
         whose values are wrong, deterministically and in whole strips:
@@ -891,7 +895,7 @@ class ConstraintCollocator(object):
         if mode == 'off':
             return None
         hot = hb.high_pressure_kernels(hsaco)
-        if not hot and mode != 'all' and not force:
+        if not hot and mode == 'hot' and not force:
             return None
         side = hsaco + '.crosscheck.json'
         try:
@@ -901,8 +905,9 @@ class ConstraintCollocator(object):
                 return verdict
         except (OSError, ValueError):
             pass
-        logger.info('kernels %s are at the register limit: checking the '
-                    'build against the instruction tape', hot)
+        logger.info('checking the build against the instruction tape%s',
+                    ' (kernels at the register limit: %s)' % hot if hot
+                    else '')
         # seeded inputs from (-1, 1); equations that are not finite there
         # (square roots, logarithms of states) are tried on narrower positive
         # ranges -- what stays non-finite must be non-finite in the build too

@@ -4,8 +4,8 @@
 (``_verified_alternative``: recorded as "pinned" entries of the plan file) and
 writes the verdicts + the updated plan file under ``gpurun_out/``.
 
-Usage: verify_zoo.py [--all] [name substring ...]
-  --all: every build, not only those at the register limit"""
+Usage: verify_zoo.py [--hot] [name substring ...]
+  --hot: only the builds at the register limit (default: every build)"""
 import json
 import logging
 import os
@@ -16,8 +16,7 @@ import time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
-if '--all' in sys.argv:
-    os.environ['OPTY_CROSS_CHECK'] = 'all'
+os.environ['OPTY_CROSS_CHECK'] = 'hot' if '--hot' in sys.argv else 'all'
 logging.basicConfig(level=logging.WARNING)
 import __graft_entry__ as ge
 from opty_amd import hip_backend as hb, launch_plan
@@ -32,7 +31,7 @@ for name, kw, col in ge.prebuilt_collocators():
     try:
         hsaco, meta = col._build_code_object()
         hot = hb.high_pressure_kernels(hsaco)
-        if not hot and os.environ.get('OPTY_CROSS_CHECK') != 'all':
+        if not hot and os.environ['OPTY_CROSS_CHECK'] == 'hot':
             continue
         col.hip
         v = col._build_verdict or {}
