@@ -232,6 +232,17 @@ def other_configs(dev, iters):
     return out
 
 
+def _build_check(col):
+    """What the verification of the code object in use said (every build is
+    held to its expression DAG, run as an instruction tape on the GPU, before
+    its handle exists: DESIGN.md 4.1)."""
+    v = getattr(col, '_build_verdict', None)
+    if not v:
+        return None
+    return {k: v.get(k) for k in ('ok', 'referee', 'worst', 'nodes',
+                                  'replacement') if v.get(k) is not None}
+
+
 def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
     pkw = problems.build(name)
     col = opty_amd.ConstraintCollocator(device=dev.index, **pkw)
@@ -252,7 +263,8 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
     out[name] = dict(
         nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
         fused_algorithmic_bytes=nbytes,
-        fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS)
+        fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS,
+        build_check=_build_check(col))
     if name.startswith('config5'):
         # one of eight node shards of the same problem (what each GPU of
         # an 8-GPU node launches): its own launch geometry, the global
@@ -667,6 +679,7 @@ def main():
                 'oversubscribed': bool(oversub),
                 'prewarm_ms': args.prewarm_ms,
                 'code_object_sha': col._kernel_meta['sha'][:16],
+                'build_check': _build_check(col),
                 'kernel_sha': kmeta['sha'][:16],
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],
