@@ -50,6 +50,11 @@ LATENCY_PATH_BYTES = 2 << 20
 #: node-invariant operations up to which a small problem evaluates them in
 #: every lane instead of launching opty_uni before every evaluation
 INLINE_UNIFORM_MAX_NODES = 64
+#: node-invariant operations that depend on `free` (a free node time
+#: interval, unknown parameters) up to which they are evaluated in the lanes,
+#: so that the ``uni`` table does not have to be refilled by a launch of
+#: opty_uni before every evaluation (_ModuleWriter._choose_inline_dynamic)
+INLINE_DYNAMIC_MAX_OPS = 48
 
 #: workgroups the runtime launches opty_uni with (OPTY_UNI_WORKGROUPS in
 #: opty_hip.cpp)
@@ -113,7 +118,7 @@ class EmitOptions(object):
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
                  cut=None, con_attach=None, forget=0, rotate=None,
-                 work_live=None):
+                 work_live=None, inline_dynamic=None):
         # 1: a strip's temporaries are dropped at every chunk boundary and
         # recomputed where needed again (bounded register pressure; the last
         # resort before a build that spills vector registers)
@@ -137,6 +142,11 @@ class EmitOptions(object):
         # fewest strips the registers allow when the even cut's
         # recomputation is what the block would wait for
         # (_ModuleWriter._automatic_work_cut; only while ``groups`` is None)
+        # node-invariant sub-expressions that depend on `free` evaluated in
+        # the lanes instead of by opty_uni before every evaluation: None =
+        # automatic (when they are few), 0 / 1 = never / always
+        self.inline_dynamic = None if inline_dynamic is None \
+            else int(inline_dynamic)
         assert cut in (None, 'even', 'work')
         self.cut = cut
         # live temporaries a strip of a work-aware cut may have (None:
@@ -255,6 +265,8 @@ class EmitOptions(object):
                 ('' if self.rotate is None else ' rotate=%d' % self.rotate) +
                 ('' if self.work_live is None
                  else ' work_live=%d' % self.work_live) +
+                ('' if self.inline_dynamic is None
+                 else ' inline_dynamic=%d' % self.inline_dynamic) +
                 ('' if self.fold_instance is None
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
@@ -500,6 +512,9 @@ class _ModuleWriter(object):
         # True: no uni[] table -- node-invariant INPUTs are scalar loads from
         # their homes and what depends on them is computed in every lane
         self.inline_uni = bool(inline_uniform)
+        self._dyn = {}
+        self.inline_dynamic = False
+        self.inline_dynamic = self._choose_inline_dynamic()
         self.uni_slot = {}          # uniform frontier node -> slot in uni[]
         self._auto = None           # (G_live, G) of group_ranges()
         self._auto_work = None      # strips of the automatic work-aware cut
@@ -515,10 +530,50 @@ class _ModuleWriter(object):
 
     def _uniform_leaf(self, i):
         """Non-constant node-invariant node: lives in the ``uni`` table
-        (without a table: only the scalar inputs are leaves)."""
-        if self.inline_uni:
-            return self.dag.uni[i] and self.dag.op[i] == ir.INPUT
-        return self.dag.uni[i] and self.dag.op[i] != ir.CONST
+        (without a table: only the scalar inputs are leaves).  Node-invariant
+        values that depend on `free` (``_dynamic``) are not table entries when
+        they are few (``inline_dynamic``): the scalars they start from are
+        leaves, loaded from their homes, and the handful of operations behind
+        them are evaluated in the lanes."""
+        d = self.dag
+        if not d.uni[i] or d.op[i] == ir.CONST:
+            return False
+        if self.inline_uni or (self.inline_dynamic and self._dynamic(i)):
+            return d.op[i] == ir.INPUT
+        return True
+
+    def _dynamic(self, i):
+        """Does node-invariant node ``i`` depend on a value that lives in
+        `free` (a free node time interval, an unknown parameter)?  Such
+        values change with every evaluation."""
+        hit = self._dyn.get(i)
+        if hit is None:
+            d = self.dag
+            if d.op[i] == ir.INPUT:
+                hit = self._scalar_source(i).startswith('free_')
+            else:
+                hit = any(self._dynamic(j) for j in d.operands(i))
+            self._dyn[i] = hit
+        return hit
+
+    def _choose_inline_dynamic(self):
+        """Node-invariant sub-expressions that depend on `free` make the whole
+        ``uni`` table dynamic: ``opty_uni`` has to run before EVERY evaluation
+        -- a launch of its own (2-5 us next to a 50-70 us evaluation) for, in
+        a variable-duration problem, ``1/h`` and a handful of products with
+        it (biped: 6 of 78 table entries, 16 operations; muscle-driven leg:
+        5 of 132, 15 operations).  When at most ``INLINE_DYNAMIC_MAX_OPS``
+        operations are behind them, they are evaluated in the lanes instead
+        and the table holds only what changes with the parameters."""
+        d, p = self.dag, self.p
+        if self.inline_uni or self.o.inline_dynamic == 0:
+            return False
+        need = [i for i in d.reachable(set(p.con_out) | set(p.jac_out))
+                if d.uni[i] and d.op[i] != ir.CONST and self._dynamic(i)]
+        if not need:
+            return False
+        ops = sum(1 for i in need if d.op[i] != ir.INPUT)
+        return self.o.inline_dynamic == 1 or ops <= INLINE_DYNAMIC_MAX_OPS
 
     def _slot(self, i):
         s = self.uni_slot.get(i)
@@ -917,7 +972,8 @@ class _ModuleWriter(object):
                 off = p.cur_offset if kind == 'cur' else p.adj_offset
                 return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
             if self._uniform_leaf(i):
-                if self.inline_uni:
+                if self.inline_uni or (self.inline_dynamic and
+                                       self._dynamic(i)):
                     return self._scalar_source(i)
                 # diagnostics (wrong values): what would the kernel cost if
                 # node-invariant operands were literals / free?

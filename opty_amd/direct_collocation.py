@@ -598,13 +598,6 @@ class ConstraintCollocator(object):
             return hsaco, meta
         best = (hsaco, meta, hb.vgpr_spills(hsaco), (source, meta), opts)
         geo = meta['geometry']
-        # what this loop ended with last time (next to the printer's first
-        # choice in the cache): reproduced without the search
-        choice_file = hsaco + '.choice.json'
-        if best[2] and opt_level is None:
-            remembered = self._remembered_choice(choice_file)
-            if remembered is not None:
-                return remembered
         # where spills appear is erratic in the cut (24-link stand-in, fused
         # strips 18 ... 28: only 20, 25 and 28 are spill-free), so the
         # narrower cuts are tried a few at a time, in parallel (hipcc is a
@@ -696,46 +689,9 @@ class ConstraintCollocator(object):
                            self._launch_blocks(),
                            ' '.join(hb.SAFE_SCHEDULER_FLAGS))
             self._built_source, self._built_options = source, best[4]
-            if opt_level is None:
-                self._remember_choice(choice_file, best[4],
-                                      list(hb.SAFE_SCHEDULER_FLAGS))
             return hsaco, meta
         self._built_source, self._built_options = best[3][0], best[4]
-        if best[0] != hsaco and opt_level is None:
-            self._remember_choice(choice_file, best[4], [])
         return best[0], best[1]
-
-    @staticmethod
-    def _remember_choice(path, opts, extra_flags):
-        import json
-        import os
-        from . import launch_plan
-        try:
-            tmp = '%s.%d.tmp' % (path, os.getpid())
-            with open(tmp, 'w') as f:
-                json.dump(dict(options=launch_plan.options_kwargs(opts),
-                               extra_flags=extra_flags), f)
-            os.replace(tmp, path)
-        except OSError:
-            pass
-
-    def _remembered_choice(self, path):
-        """``(hsaco, meta)`` of the build the spill loop chose the last time
-        it started from the same first build, or None."""
-        import json
-        try:
-            with open(path) as f:
-                rec = json.load(f)
-            opts = EmitOptions(**rec['options'])
-            flags = tuple(rec.get('extra_flags', ()))
-        except (OSError, ValueError, TypeError, AssertionError, KeyError):
-            return None
-        source, meta = self._emit(opts)
-        hsaco = hb.compile_module(source, self.tmp_dir,
-                                  self.show_compile_output,
-                                  extra_flags=flags)
-        self._built_source, self._built_options = source, opts
-        return hsaco, meta
 
     def _pinned_build(self):
         """``(EmitOptions, {'opt_level': .., 'extra_flags': ..})`` of the
@@ -894,6 +850,8 @@ class ConstraintCollocator(object):
         mode = os.environ.get('OPTY_CROSS_CHECK', '').lower()
         if mode == 'off':
             return None
+        if hb.load_library().opty_hip_device_count() <= 0:
+            return None         # creating the handle says what is missing
         hot = hb.high_pressure_kernels(hsaco)
         if not hot and mode == 'hot' and not force:
             return None

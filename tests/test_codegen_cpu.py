@@ -691,11 +691,21 @@ def test_small_problems_are_single_launch_modules():
         assert meta['num_uniform'] == 0 and not meta['uniform_dynamic']
         assert 'uni_c[' not in src
         off = ConstraintCollocator(
-            emit_options=EmitOptions(inline_uniform=0, fold_instance=0),
+            emit_options=EmitOptions(inline_uniform=0, inline_dynamic=0,
+                                     fold_instance=0),
             **problems.build(name))
         src0, meta0 = off.generate_source()
         assert meta0['num_uniform'] > 0 and meta0['uniform_dynamic']
         assert not meta0['inst_folded']
+        # with a table: only what does NOT depend on `free` is in it -- the
+        # few operations behind 1/h or an unknown parameter are evaluated in
+        # the lanes, and opty_uni does not run before every evaluation
+        part = ConstraintCollocator(
+            emit_options=EmitOptions(inline_uniform=0, fold_instance=0),
+            **problems.build(name))
+        src1, meta1 = part.generate_source()
+        assert not meta1['uniform_dynamic']
+        assert meta1['num_uniform'] < meta0['num_uniform']
     # the same systems at a size that is not small keep both
     big = ConstraintCollocator(**dict(
         problems.CONFIGS['config2_pendulum'][0](num_nodes=100001)))
