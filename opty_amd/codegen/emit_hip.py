@@ -1785,17 +1785,16 @@ def emit_module(prog, opts=None, node_blocks=None):
     nt_alone = opts.con_nt != 0
     nt_fused = opts.con_nt == 1 or (opts.con_nt is None and
                                     con_bytes > CON_CACHE_BYTES)
-    # Small problems (everything one evaluation moves fits the runtime's
-    # latency path, OPTY_LATENCY_PATH_BYTES: BASELINE config 2) cost what
-    # their launches cost, so the instance tails ride in the main kernels'
-    # launch: one more workgroup instead of one more kernel.
+    # The instance tails ride in the main kernels' launch: one more workgroup
+    # instead of one more kernel.  Small problems (BASELINE config 2) cost
+    # what their launches cost; and next to a 50-70 us evaluation of a
+    # gait-like problem the launch of opty_inst is still 5-10 % (biped:
+    # 0.0767 -> 0.068 ms per evaluation with its 16 periodicity constraints
+    # folded).  (Node shards evaluate the tails through opty_inst, once, on
+    # the rank that assembles a vector.)
     fold = opts.fold_instance
     if fold is None:
-        per_block = 8*64*int(node_blocks or 0)
-        fold = bool(node_blocks and prog.inst_con_out) and \
-            per_block*(prog.P + prog.M) <= LATENCY_PATH_BYTES and \
-            per_block*(prog.P + prog.M + len(w._kernel_rows(
-                fused_groups, con_of))) <= LATENCY_PATH_BYTES
+        fold = bool(node_blocks and prog.inst_con_out)
     folded = w.inst_lines() if (fold and prog.inst_con_out) else None
     for key, name, grp, cons, wpw, nt in (
             ('con', 'opty_con', [[(0, 0)]]*len(alone_sets), alone_sets, 1,

@@ -669,8 +669,8 @@ def test_small_problems_are_single_launch_modules():
     workgroup, ``inst_folded``), and a node-invariant table that opty_uni
     would refill before every evaluation (unknown parameters, variable
     duration) is not used at all -- those values are computed in every lane.
-    Large launches keep the table and the separate opty_inst launch, and
-    their source does not change."""
+    Large launches keep the table; their instance tails are folded as
+    well."""
     # BASELINE config 2: 4 instance constraints, a static table
     col = ConstraintCollocator(**problems.build('config2_pendulum'))
     src, meta = col.generate_source()
@@ -706,10 +706,16 @@ def test_small_problems_are_single_launch_modules():
         src1, meta1 = part.generate_source()
         assert not meta1['uniform_dynamic']
         assert meta1['num_uniform'] < meta0['num_uniform']
-    # the same systems at a size that is not small keep both
+    # the tails are folded at every size (a launch of opty_inst is 5-10 % of
+    # a 50-70 us evaluation too); the table stays a table
     big = ConstraintCollocator(**dict(
         problems.CONFIGS['config2_pendulum'][0](num_nodes=100001)))
     src, meta = big.generate_source()
+    assert meta['inst_folded'] and meta['num_uniform'] > 0
+    unfolded = ConstraintCollocator(
+        emit_options=EmitOptions(fold_instance=0), **dict(
+            problems.CONFIGS['config2_pendulum'][0](num_nodes=100001)))
+    src, meta = unfolded.generate_source()
     assert not meta['inst_folded'] and 'blockIdx.x >= ((node_end' not in src
     # a table too large to recompute per lane stays a table
     col = ConstraintCollocator(**problems.build(
