@@ -94,6 +94,10 @@ FUSED_STRIPS_PER_SQRT_ENTRY = 0.286
 #: fine with plain stores, and the 176 MB of N = 10^6)
 CON_CACHE_BYTES = 128 << 20
 
+#: doubles between the end of a launch's Jacobian values and the wave records
+#: of ``EmitOptions.trace``
+TRACE_OFFSET = 4096
+
 KERNEL_PARAMS = (
     'const double *__restrict__ free_, const double *__restrict__ known_traj, '
     'const double *__restrict__ params, const double *__restrict__ uni_c, '
@@ -118,7 +122,45 @@ class EmitOptions(object):
                  fused_groups=None, small_flush='flat', con_split='work',
                  fold_instance=None, inline_uniform=None, dear_first=0,
                  cut=None, con_attach=None, forget=0, rotate=None,
-                 work_live=None, inline_dynamic=None):
+                 work_live=None, inline_dynamic=None, order=None, trace=0,
+                 park=0, park_live=215, strips=None):
+        # explicit cut of a node-major block (experiments, plan files):
+        # ``'96:160;160:348+0:96'`` = two waves, the second one with two
+        # strips (boundaries on 16-entry lines; every entry covered once)
+        self.strips = strips
+        # LDS parking (line-mode Jacobian waves): a wave whose live
+        # temporaries exceed the register file keeps up to ``park`` of them
+        # in LDS rows of its own (64 doubles each, behind its ring tile)
+        # instead of being cut into two strips that both evaluate what they
+        # share.  The printer plans the wave (_WavePlan): the order in which
+        # the entries' expressions are evaluated (memory order, or cheapest
+        # next -- whichever keeps fewer values alive; the ring tile takes
+        # them in memory order all the same), then a farthest-next-use
+        # eviction over the straight-line code with ``park_live`` doubles in
+        # registers.  0 = off
+        self.park = int(park)
+        self.park_live = int(park_live)
+        # profiling aid (never used by the product): every wave records its
+        # start / end (wall_clock64, shader cycles), its strip and where it
+        # ran behind the Jacobian values -- ``jac`` must hold
+        # TRACE_OFFSET + 4 x (waves of the launch) more doubles
+        # (tools/wave_timeline.py)
+        self.trace = int(trace)
+        # dispatch order of a launch's workgroups: 'block' = the workgroups
+        # of one 64-node block back to back (they read the same slab and
+        # write interleaved strips of the same rows: what a store-bound
+        # block wants), 'class' = strip class by strip class, the longest
+        # waves of ALL blocks first (longest-processing-time order: a launch
+        # whose waves differ 5x in length is packed onto the SIMDs like a
+        # list schedule instead of leaving the long waves of the last blocks
+        # to run alone at the end).  None = 'block'
+        # 'tail': block by block, except that the last blocks of a launch
+        # (as many as put one resident set of long waves on the chip) are
+        # dispatched class by class -- their long waves first, the short
+        # ones last: a launch in 'block' order ends with the long waves of
+        # its last blocks running alone
+        assert order in (None, 'block', 'class', 'tail')
+        self.order = order
         # 1: a strip's temporaries are dropped at every chunk boundary and
         # recomputed where needed again (bounded register pressure; the last
         # resort before a build that spills vector registers)
@@ -271,7 +313,12 @@ class EmitOptions(object):
                  else ' fold_instance=%d' % self.fold_instance) +
                 ('' if self.inline_uniform is None
                  else ' inline_uniform=%d' % self.inline_uniform) +
-                (' dear_first=1' if self.dear_first else ''))
+                (' dear_first=1' if self.dear_first else '') +
+                ('' if self.order is None else ' order=%s' % self.order) +
+                (' trace=1' if self.trace else '') +
+                (' park=%d/%d' % (self.park, self.park_live)
+                 if self.park else '') +
+                ('' if not self.strips else ' strips=%s' % self.strips))
 
 
 def _lit(v):
@@ -503,6 +550,233 @@ def _max_live(dag, chunks, is_leaf):
     return peak
 
 
+#: LDS parking of a planned wave (``EmitOptions.park``): plain 8-byte LDS
+#: accesses, lane-linear (conflict-free)
+_PARK_HELPERS = '''\
+__device__ __forceinline__ void opty_park(double *park, int slot, int lane,
+                                          double v) {
+    park[slot*OPTY_WAVE + lane] = v;
+}
+__device__ __forceinline__ double opty_unpark(const double *park, int slot,
+                                              int lane_z) {
+    return park[slot*OPTY_WAVE + lane_z];
+}'''
+
+
+class _WavePlan(object):
+    """Straight-line schedule of ONE wave with LDS parking
+    (``EmitOptions.park``).
+
+    ``targets``: what the wave has to produce, in memory order --
+    ``('c', j, root)`` a constraint row (stored when computed) or
+    ``('e', k, root)`` the k-th ring write of the wave; ``chunk_of[k]`` = the
+    flush after which ring write k's row may be overwritten, i.e. the ring
+    writes of chunk c are issued, in order, once ALL its targets are
+    computed, followed by the chunk's flush.  ``is_leaf(i)``: node ``i`` is
+    fetched, not computed (constants, slab inputs, node-invariant values).
+
+    The plan is a list of events ``('op', node, partner)`` (``partner``: the
+    cos / sin of the same argument produced by the same ``sincos``),
+    ``('con', j)``, ``('chunk', c)``; ``parks[t]`` = values stored to their
+    LDS slot after event ``t`` (``[(node, slot)]``), ``slot_of[node]`` where a
+    parked value is reloaded from.  A value sits in a register from its
+    computation (or reload) to its eviction or last use; when more than
+    ``budget`` are alive the one whose next use is farthest away goes
+    (Belady): computed once, stored once, reloaded once per later use
+    cluster."""
+
+    def __init__(self, dag, targets, chunks, is_leaf, budget, order=None):
+        self.dag = d = dag
+        self.targets = targets
+        self.chunks = chunks            # chunk c -> list of target indices
+        self.is_leaf = is_leaf
+        roots = [t[2] for t in targets]
+        self.need = [i for i in d.reachable(
+            {r for r in roots if not is_leaf(r)}) if not is_leaf(i)]
+        self.bit = {i: k for k, i in enumerate(self.need)}
+        self._cone = {}
+        best = None
+        for how in ((order,) if order else ('memory', 'cheapest')):
+            events = self._schedule(how)
+            peak = self._belady(events, None)[3]
+            if best is None or peak < best[0]:
+                best = (peak, how, events)
+        self.peak, self.order, self.events = best
+        self.parks, self.slot_of, self.slots, _ = self._belady(self.events,
+                                                               budget)
+
+    # -- order ---------------------------------------------------------------
+    def _cone_mask(self, root):
+        m = self._cone.get(root)
+        if m is None:
+            m = 0
+            if not self.is_leaf(root):
+                for i in self.dag.reachable([root]):
+                    k = self.bit.get(i)
+                    if k is not None:
+                        m |= 1 << k
+            self._cone[root] = m
+        return m
+
+    def _partner(self, i, done):
+        d = self.dag
+        if d.op[i] not in ('sin', 'cos'):
+            return None
+        other = 'cos' if d.op[i] == 'sin' else 'sin'
+        j = d._memo.get((other, d.args[i]))
+        if j is None or j not in self.bit or j in done:
+            return None
+        return j
+
+    def _schedule(self, how):
+        d = self.dag
+        T = len(self.targets)
+        work = [k for k in range(T)
+                if not self.is_leaf(self.targets[k][2])]
+        mask = {k: self._cone_mask(self.targets[k][2]) for k in work}
+        done, donemask = set(), 0
+        events = []
+        finished = [False]*T
+        for k in range(T):
+            if k not in mask:
+                finished[k] = True      # nothing to compute
+        chunk_left = [sum(1 for k in c if not finished[k])
+                      for c in self.chunks]
+        chunk_of = {}
+        for c, ks in enumerate(self.chunks):
+            for k in ks:
+                chunk_of[k] = c
+        next_chunk = 0
+
+        def flush_ready():
+            nonlocal next_chunk
+            while next_chunk < len(self.chunks) and \
+                    chunk_left[next_chunk] == 0:
+                events.append(('chunk', next_chunk))
+                next_chunk += 1
+
+        flush_ready()
+        rest = list(work)
+        while rest:
+            if how == 'memory':
+                k = rest[0]
+            else:
+                # cheapest next: the target that needs the fewest values
+                # that are not there yet (constraint rows before entries,
+                # then memory order)
+                k = min(rest, key=lambda k: (
+                    (mask[k] & ~donemask).bit_count(), k))
+            rest.remove(k)
+            events.append(('begin', k))
+            root = self.targets[k][2]
+            stack = [(root, False)]
+            while stack:
+                i, ready = stack.pop()
+                if i in done or self.is_leaf(i):
+                    continue
+                if not ready:
+                    stack.append((i, True))
+                    for j in reversed(d.operands(i)):
+                        if j not in done and not self.is_leaf(j):
+                            stack.append((j, False))
+                    continue
+                pair = self._partner(i, done)
+                events.append(('op', i, pair))
+                for v in (i, pair):
+                    if v is not None:
+                        done.add(v)
+                        donemask |= 1 << self.bit[v]
+            if self.targets[k][0] == 'c':
+                events.append(('con', k))
+            finished[k] = True
+            if k in chunk_of:
+                chunk_left[chunk_of[k]] -= 1
+            flush_ready()
+        flush_ready()
+        assert next_chunk == len(self.chunks)
+        return events
+
+    # -- registers -----------------------------------------------------------
+    def _uses(self, events):
+        """``{node: [event indices that read it]}`` (ascending)."""
+        d = self.dag
+        uses = {}
+        for t, ev in enumerate(events):
+            if ev[0] == 'op':
+                for j in set(d.operands(ev[1])):
+                    if not self.is_leaf(j):
+                        uses.setdefault(j, []).append(t)
+            elif ev[0] == 'con':
+                r = self.targets[ev[1]][2]
+                if not self.is_leaf(r):
+                    uses.setdefault(r, []).append(t)
+            elif ev[0] == 'chunk':
+                for k in self.chunks[ev[1]]:
+                    r = self.targets[k][2]
+                    if not self.is_leaf(r):
+                        u = uses.setdefault(r, [])
+                        if not u or u[-1] != t:
+                            u.append(t)
+        return uses
+
+    def _belady(self, events, budget):
+        """``(parks, slot_of, slots, peak)``; ``budget=None``: only the peak
+        number of simultaneously live values."""
+        import bisect
+        d = self.dag
+        uses = self._uses(events)
+
+        def next_use(v, t):
+            u = uses.get(v, ())
+            k = bisect.bisect_right(u, t)
+            return u[k] if k < len(u) else None
+
+        inreg, slot_of, taken, stored = set(), {}, set(), set()
+        parks, slots, peak = {}, 0, 0
+        self.drops = drops = {}
+        for t, ev in enumerate(events):
+            if ev[0] == 'op':
+                reads = {j for j in d.operands(ev[1])
+                         if not self.is_leaf(j)}
+                made = [v for v in ev[1:] if v is not None]
+            elif ev[0] == 'con':
+                r = self.targets[ev[1]][2]
+                reads, made = ({r} if not self.is_leaf(r) else set()), []
+            else:
+                # the ring writes of a chunk are issued one after the other:
+                # a parked value is reloaded for its own store only
+                reads, made = set(), []
+            inreg |= reads
+            inreg.update(made)
+            peak = max(peak, len(inreg))
+            for v in list(inreg):
+                if next_use(v, t) is None:
+                    inreg.discard(v)
+            for v in [v for v in stored if next_use(v, t) is None]:
+                # (slot_of[v] stays recorded: its reloads lie behind)
+                stored.discard(v)
+                taken.discard(slot_of[v])
+            if budget is None:
+                continue
+            while len(inreg) > budget:
+                cand = [v for v in inreg if v not in reads and v not in made]
+                if not cand:
+                    break
+                v = max(cand, key=lambda v: (next_use(v, t), v))
+                inreg.discard(v)
+                drops.setdefault(t, []).append(v)
+                if v not in stored:
+                    sl = 0
+                    while sl in taken:
+                        sl += 1
+                    taken.add(sl)
+                    slot_of[v] = sl
+                    stored.add(v)
+                    slots = max(slots, sl + 1)
+                    parks.setdefault(t, []).append((v, sl))
+        return parks, slot_of, slots, peak
+
+
 class _ModuleWriter(object):
 
     def __init__(self, prog, opts, inline_uniform=False):
@@ -522,6 +796,8 @@ class _ModuleWriter(object):
         self._dense = {}            # unit range -> estimated live values
         self._wcost = {}            # weighted work of entry ranges
         self._con_nt = False        # constraint stores of the kernel in print
+        self._park_rows = 0         # LDS rows the planned waves park values in
+        self._plans = []
 
     # -- leaves -------------------------------------------------------------
     def _is_vec_input(self, i):
@@ -815,6 +1091,16 @@ class _ModuleWriter(object):
         With ``groups=None`` G is ``auto_groups()[1]``.  Returns a list of
         groups, each a list of ``(e0, e1)`` strips in evaluation order."""
         P, K = self.p.P, self.o.chunk
+        if self.o.strips and self.line_mode() and count is None:
+            groups = [[tuple(int(x) for x in rg.split(':'))
+                       for rg in grp.split('+')]
+                      for grp in self.o.strips.split(';')]
+            cover = sorted(rg for grp in groups for rg in grp)
+            assert cover[0][0] == 0 and cover[-1][1] == P and all(
+                a[1] == b[0] for a, b in zip(cover, cover[1:])) and all(
+                    e0 % 16 == 0 and e1 > e0 for e0, e1 in cover), cover
+            self._auto = (len(groups), len(groups))
+            return groups
         unit = 16 if self.line_mode() else K
         nunits = max(1, P//unit if self.line_mode() else (P + K - 1)//K)
         two = bool(self.o.interleave) and self.line_mode()
@@ -986,7 +1272,20 @@ class _ModuleWriter(object):
             return None
 
         body = _Body(d, needed, leaf, self.o.fast_trig)
-        for j in con_rows:
+        # LDS parking: the wave is planned as a whole (constraint rows
+        # included) when it is worth it -- its temporaries in memory order
+        # would not fit the registers
+        planned = bool(self.o.park and self.line_mode() and
+                       self.o.ablate is None and not self.o.forget and
+                       any(e1 > e0 for e0, e1 in grp))
+        if planned:
+            est = _max_live(d, [[p.con_out[j]] for j in con_rows] + [
+                [p.jac_out[v % p.P] for v in range(a, b)]
+                for e0, e1 in grp if e1 > e0
+                for a, b in self._chunks(e0, self._virtual_end(e1))],
+                lambda i: leaf(i) is not None)
+            planned = est > self.o.park_live
+        for j in ([] if planned else con_rows):
             body.new_scope()      # fetches hoisted per row, not per kernel
             ref = body.emit(p.con_out[j])
             if self._con_nt:
@@ -1008,6 +1307,9 @@ class _ModuleWriter(object):
         strips = [rg for rg in grp if rg[1] > rg[0]]
         if strips and self.line_mode():
             body.lines.append('const int b0 = opty_line_phase(jrow);')
+        if strips and planned:
+            self._planned_strips(body, strips, con_rows, nv, R)
+            strips = []
         for e0, e1 in strips:
             body.lines.append('// strip %d %d' % (e0, e1))
             if self.line_mode():
@@ -1020,6 +1322,105 @@ class _ModuleWriter(object):
                 self._strip_simple(body, e0, e1, value, nv)
         body.end_scope()
         return body.lines
+
+    def _planned_strips(self, body, strips, con_rows, nv, R):
+        """The wave's code from a :class:`_WavePlan`: constraint rows and
+        entry expressions in the planned order, long-lived values parked in
+        the wave's LDS rows (``park``), ring writes and flushes chunk by
+        chunk in memory order."""
+        p, d = self.p, self.dag
+        K = self.o.chunk
+        targets = [('c', j, p.con_out[j]) for j in con_rows]
+        chunks, flush = [], []
+        for e0, e1 in strips:
+            for c0 in range(e0, e1 + 15, K):
+                c1 = min(c0 + K, e1 + 15)
+                ks = []
+                for v in range(c0, c1):
+                    ks.append(len(targets))
+                    targets.append(('e', v, p.jac_out[v % p.P]))
+                chunks.append(ks)
+                flush.append((e0, e1, c0, c1))
+
+        def is_leaf(i):
+            return d.op[i] == ir.CONST or body.leaf(i) is not None
+
+        plan = _WavePlan(d, targets, chunks, is_leaf, self.o.park_live)
+        self._park_rows = max(self._park_rows, plan.slots)
+        self._plans.append(dict(strips=strips, order=plan.order,
+                                peak=plan.peak, slots=plan.slots,
+                                ops=sum(1 for e in plan.events
+                                        if e[0] == 'op')))
+        lines = body.lines
+        reloads = [0]
+
+        def operand(j):
+            if d.op[j] == ir.CONST or j in body.scope or j in body.done:
+                return
+            if body.leaf(j) is not None:
+                body._fetch(j)
+                return
+            reloads[0] += 1
+            name = 'v%d_r%d' % (j, reloads[0])
+            lines.append('const double %s = opty_unpark(park, %d, lane_z);'
+                         % (name, plan.slot_of[j]))
+            body.done[j] = name
+
+        for t, ev in enumerate(plan.events):
+            if ev[0] == 'begin':
+                body.new_scope()
+            elif ev[0] == 'op':
+                i, pair = ev[1], ev[2]
+                for j in d.operands(i):
+                    operand(j)
+                if d.op[i] in ('sin', 'cos'):
+                    a = body.ref(d.args[i][0])
+                    if pair is not None:
+                        s_id, c_id = (i, pair) if d.op[i] == 'sin' \
+                            else (pair, i)
+                        sn, cn = body._name(s_id), body._name(c_id)
+                        lines.append('double %s, %s; %ssincos(%s, &%s, &%s);'
+                                     % (sn, cn, body.trig, a, sn, cn))
+                        body.done[s_id], body.done[c_id] = sn, cn
+                    else:
+                        name = body._name(i)
+                        lines.append('const double %s = %s%s(%s);'
+                                     % (name, body.trig, d.op[i], a))
+                        body.done[i] = name
+                else:
+                    body._emit_node(i)
+            elif ev[0] == 'con':
+                j, root = targets[ev[1]][1], targets[ev[1]][2]
+                operand(root)
+                ref = body.ref(root)
+                if self._con_nt:
+                    lines.append('if (valid) __builtin_nontemporal_store(%s, '
+                                 '&con[%dLL*con_stride + node]);' % (ref, j))
+                else:
+                    lines.append('if (valid) con[%dLL*con_stride + node] = '
+                                 '%s;' % (j, ref))
+            else:
+                c = ev[1]
+                e0, e1, c0, c1 = flush[c]
+                if c0 == e0:
+                    lines.append('// strip %d %d' % (e0, e1))
+                body.new_scope()
+                for k in chunks[c]:
+                    v, root = targets[k][1], targets[k][2]
+                    if is_leaf(root):
+                        val = body.emit(root)
+                    elif root in body.done:
+                        val = body.done[root]
+                    else:       # parked: straight from its row to the ring
+                        val = 'opty_unpark(park, %d, lane_z)' \
+                            % plan.slot_of[root]
+                    lines.append('ring[%d + lane] = %s;' % ((v % R)*TS, val))
+                self._flush_chunk(body, e0, e1, c0, c1, nv, R, p.P)
+            for v, sl in plan.parks.get(t, ()):
+                lines.append('opty_park(park, %d, lane, %s);'
+                             % (sl, body.done[v]))
+            for v in plan.drops.get(t, ()):
+                body.done.pop(v, None)
 
     def _whole_block_strip(self, grp):
         """A wave that evaluates the WHOLE block of a small (P < 64)
@@ -1067,21 +1468,27 @@ class _ModuleWriter(object):
                 body.begin_entry()
                 body.lines.append('ring[%d + lane] = %s;'
                                   % ((v % R)*TS, value(v % P)))
-            body.lines.append('opty_wave_sync();')
-            nlp = 1
-            while 16*nlp < c1 - c0:
-                nlp *= 2
-            body.lines.append(
-                'opty_flush_lines<%d, %d, %d>(ring, %s, %d, %s, %d, %d,'
-                ' %d, %d, %d, %s, lane);' % (
-                    nlp, R, self.o.flush_unroll, jrow, P, b0, c0 - 15,
-                    (c0 - 15) % R, e0, e1, c1, nv))
-            if e0 == 0 and c0 == 0:
-                assert c1 >= 15
-                if self.o.ablate != 'compute_only':
-                    body.lines.append('opty_head_piece<%d>(ring, %s, '
-                                      '%d, %s, lane);' % (R, jrow, P, b0))
-            body.lines.append('opty_wave_sync();')
+            self._flush_chunk(body, e0, e1, c0, c1, nv, R, P, jrow, b0)
+
+    def _flush_chunk(self, body, e0, e1, c0, c1, nv, R, P, jrow='jrow',
+                     b0='b0'):
+        """The flush after the ring writes of the chunk ``[c0, c1)`` of the
+        strip ``[e0, e1)``."""
+        body.lines.append('opty_wave_sync();')
+        nlp = 1
+        while 16*nlp < c1 - c0:
+            nlp *= 2
+        body.lines.append(
+            'opty_flush_lines<%d, %d, %d>(ring, %s, %d, %s, %d, %d,'
+            ' %d, %d, %d, %s, lane);' % (
+                nlp, R, self.o.flush_unroll, jrow, P, b0, c0 - 15,
+                (c0 - 15) % R, e0, e1, c1, nv))
+        if e0 == 0 and c0 == 0:
+            assert c1 >= 15
+            if self.o.ablate != 'compute_only':
+                body.lines.append('opty_head_piece<%d>(ring, %s, '
+                                  '%d, %s, lane);' % (R, jrow, P, b0))
+        body.lines.append('opty_wave_sync();')
 
     def _strip_csr(self, body, e0, e1, value, nv):
         """Row-sorted layout: equation j's L entries of the wave's 64 nodes
@@ -1192,8 +1599,7 @@ class _ModuleWriter(object):
     // all workgroups of one 64-node block (same input slab, interleaved
     // strips of the same output rows) go to the SAME XCD / L2, back to back.
     const long long xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const long long blk = (slot/{sets})*8 + xcd;
-    const int grp = (int)({rot} % {sets})*{W} + wave;
+    {mapping}
     if (blk >= nblk) return;
     const long long node0 = node_begin + blk*64;
     const long long node = node0 + lane;
@@ -1231,7 +1637,7 @@ class _ModuleWriter(object):
         slab_of = {r: k for k, r in enumerate(rows)}
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
         if W is None:
-            if G <= 4 and any(con_of_group) and \
+            if G <= 4 and any(con_of_group) and not self.o.strips and \
                     self.o.cut != 'work' and self._auto_work is None and \
                     any(e1 > e0 for grp in groups for e0, e1 in grp):
                 # the fused kernel of a small block: its few waves form ONE
@@ -1250,9 +1656,12 @@ class _ModuleWriter(object):
         while W > 1 and (len(rows) + W*ring_rows)*TS*8 > 160*1024:
             W -= 1
         sets = (G + W - 1)//W
+        self._park_rows = 0
         bodies = [self._group_body(grp, con_of_group[g], slab_of)
                   if keep[g] else []
                   for g, grp in enumerate(groups)]
+        park_rows = self._park_rows
+        self.uses_park = getattr(self, 'uses_park', False) or park_rows > 0
         # Ring tiles only for the waves that stage Jacobian entries: the
         # constraint waves come last, so in every workgroup the ring users
         # are its first waves (tile index == wave index) and a workgroup of
@@ -1266,7 +1675,8 @@ class _ModuleWriter(object):
             rings = max(rings, sum(mine))
         if W == 1:
             rings = 1           # one size per kernel: nothing to share
-        lds_doubles = max(1, (len(rows) + rings*ring_rows)*TS)
+        lds_doubles = max(1, (len(rows) + rings*ring_rows)*TS +
+                          W*park_rows*WAVE)
         occ = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (
             self.o.occupancy, self.o.occupancy) if self.o.occupancy else ''
         src = ['extern "C" __global__ void __launch_bounds__(%d)%s'
@@ -1293,9 +1703,44 @@ class _ModuleWriter(object):
             # biped's Jacobian kernel with 4 work-aware strips: 0.104 ms,
             # with 5: 0.066 ms).
             rot = '(%s + slot/%d)' % (rot, sets)
-        src += [self._PROLOGUE.format(sets=sets, W=W, P=self.p.P,
-                                      slab=len(rows)*TS, ring=ring_rows*TS,
-                                      rot=rot)]
+        if self.o.order == 'tail' and sets > 1:
+            # block by block, then the last ``tail`` blocks of every XCD
+            # class by class (sets sorted longest first)
+            tail = max(1, RESIDENT_WAVES//(8*max(1, sets - 1)))
+            mapping = (
+                'const long long nslot = (nblk + 7) >> 3;\n'
+                '    const long long ntail = nslot < {tail} ? nslot : {tail};\n'
+                '    const long long nhead = nslot - ntail;\n'
+                '    const long long stail = slot - nhead*{sets};\n'
+                '    const long long blk = (stail < 0 ? slot/{sets} : '
+                'nhead + stail % ntail)*8 + xcd;\n'
+                '    const int grp = (int)(stail < 0 ? slot % {sets} : '
+                'stail/ntail)*{W} + wave;').format(W=W, sets=sets, tail=tail)
+        elif self._class_major():
+            # strip class by strip class: workgroup set s of every block
+            # before set s + 1 of any (the printer sorted the sets longest
+            # first); a block's workgroups stay on one XCD
+            mapping = ('const long long nslot = (nblk + 7) >> 3;\n'
+                       '    const long long blk = (slot % nslot)*8 + xcd;\n'
+                       '    const int grp = (int)(slot/nslot)*{W} + wave;'
+                       ).format(W=W)
+        else:
+            mapping = ('const long long blk = (slot/{sets})*8 + xcd;\n'
+                       '    const int grp = (int)({rot} % {sets})*{W} + wave;'
+                       ).format(sets=sets, W=W, rot=rot)
+        src += [self._PROLOGUE.format(P=self.p.P, mapping=mapping,
+                                      slab=len(rows)*TS, ring=ring_rows*TS)]
+        if park_rows:
+            # the wave's parking rows (behind the ring tiles); reloads go
+            # through ``lane_z`` == lane, which the compiler cannot prove, so
+            # that it neither forwards the parked value from its register
+            # (which would keep it alive) nor moves a reload above its store
+            src += ['    double *const park = lds + %d + wave*%d;'
+                    % ((len(rows) + rings*ring_rows)*TS, park_rows*WAVE),
+                    '    const int lane_z = lane + (int)(N >> 62);']
+        if self.o.trace:
+            src += ['    const long long tr_w0 = wall_clock64();',
+                    '    const long long tr_c0 = __builtin_readcyclecounter();']
         src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
         if G == 1:
             src += ['    ' + ln for ln in bodies[0]]
@@ -1307,6 +1752,19 @@ class _ModuleWriter(object):
                 src.append('    } break;')
             src.append('    default: break;')
             src.append('    }')
+        if self.o.trace:
+            src += [
+                '    if (lane == 0 && jac) {',
+                '        long long *tr = reinterpret_cast<long long *>(jac + '
+                'ncn*%dLL + %d) + ((long long)blockIdx.x*%d + wave)*4;'
+                % (self.p.P, TRACE_OFFSET, W),
+                '        tr[0] = tr_w0; tr[1] = wall_clock64();',
+                '        tr[2] = ((long long)grp << 40) | blk;',
+                '        tr[3] = ((long long)(__builtin_readcyclecounter() - '
+                'tr_c0) << 24) | (long long)(__builtin_amdgcn_s_getreg('
+                'GETREG_IMMED(3, 0, 20)) << 16) | (long long)'
+                '__builtin_amdgcn_s_getreg(GETREG_IMMED(15, 0, 4));',
+                '    }']
         src.append('}')
         text = '\n'.join(src)
         # sha of this kernel's own source: profiles/traffic.json keys the PMC
@@ -1314,7 +1772,15 @@ class _ModuleWriter(object):
         # collected on and not with a change elsewhere in the module
         return text, dict(name=name, groups=G, waves_per_wg=W,
                           wgs_per_block=sets, lds_bytes=lds_doubles*8,
+                          park_rows=park_rows,
                           sha=hashlib.sha256(text.encode()).hexdigest())
+
+    def _class_major(self):
+        # (None = 'block': measured, profiles/r05_wave_timelines.txt -- the
+        # class order pays for the muscle-driven leg, whose long waves are
+        # fewer than the SIMDs, and costs the biped, whose store-only class
+        # then runs alone at the end: a choice for the launch-plan tuner)
+        return self.o.order in ('class', 'tail')
 
     @staticmethod
     def _waves_per_workgroup(slab_rows, ring_rows, lds_per_cu=160*1024):
@@ -1762,6 +2228,14 @@ def emit_module(prog, opts=None, node_blocks=None):
             return sum(w._strip_cost(e0, e1) for e0, e1 in grp if e1 > e0)
         groups = sorted(groups, key=work, reverse=True)
         fused_jac = sorted(fused_jac, key=work, reverse=True)
+    elif w._class_major():
+        # longest strips first (what the dispatch order of
+        # ``EmitOptions.order`` = 'class' hands out first)
+        def work(grp):
+            return sum(w._weighted_cost(e0, e1) + STORE_WEIGHT*(e1 - e0)
+                       for e0, e1 in grp if e1 > e0)
+        groups = sorted(groups, key=work, reverse=True)
+        fused_jac = sorted(fused_jac, key=work, reverse=True)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
     # waves ride in the shadow of the store-bound Jacobian waves.  Where the
@@ -1819,6 +2293,8 @@ def emit_module(prog, opts=None, node_blocks=None):
             '// %s' % opts.key(),
             '#define OPTY_STORE_AUX %d' % opts.store_aux,
             '#include "opty_device.h"', '']
+    if getattr(w, 'uses_park', False):
+        head += [_PARK_HELPERS, '']
     source = '\n'.join(head + parts)
     meta = dict(kernels=kernels,
                 groups=[[list(rg) for rg in grp] for grp in groups],
@@ -1829,4 +2305,6 @@ def emit_module(prog, opts=None, node_blocks=None):
                 inst_folded=bool(folded),
                 con_attached=bool(any(attached)),
                 sha=hashlib.sha256(source.encode()).hexdigest())
+    if w._plans:
+        meta['plans'] = w._plans
     return source, meta

@@ -21,9 +21,11 @@ overrides the path, ``OPTY_LAUNCH_PLANS=off`` disables lookups)::
                         "jac": {...}},
         "nodes": 99999, "device": "AMD Instinct MI355X", "problem": "..."}}
 
-* problem sha: sha-256 of the module the printer emits with its default
-  options for "large launches" -- it changes with the equations, the
-  discretisation and the printer itself, so a stale plan is never applied;
+* problem sha: structural sha-256 of the collocation program (the expression
+  DAG of every output, input homes, discretisation, layout: ``problem_sha``)
+  -- it changes with the equations, the discretisation and the lowering, so a
+  stale plan is never applied; ``PLAN_EPOCH`` is bumped when a printer change
+  alters what recorded options MEAN;
 * launch bucket: ``round(log2(64-node blocks of one launch))``, capped at 12
   (launches of 4096 blocks and more fill the chip many times over and share
   one optimum; a 196-block node shard does not);
@@ -69,8 +71,73 @@ def bucket(node_blocks):
     return min(12, int(round(math.log2(max(1, int(node_blocks))))))
 
 
+#: bumped when the MEANING of recorded options changes (a plan measured for
+#: one printer's "groups=5" must not be applied by a printer that cuts five
+#: strips elsewhere); printer changes that keep the meaning keep the plans
+PLAN_EPOCH = 1
+
+
 def problem_sha(prog):
-    """Identity of a collocation program for the plan file."""
+    """Identity of a collocation program for the plan file: a structural
+    hash of what the printer is given -- the expression DAG behind every
+    output, the trajectory rows / parameters / interval homes, the
+    discretisation offsets and the output layout.  It changes with the
+    equations, the discretisation and the lowering, NOT with the printer (up
+    to r04 the key was the sha of the emitted module: every printer change
+    orphaned every measured plan, and computing it meant printing the module,
+    seconds for a biped).  Memoised on the program."""
+    hit = getattr(prog, '_plan_sha', None)
+    if hit is not None:
+        return hit
+    import hashlib
+    d = prog.dag
+    memo = {}
+
+    def node(root):
+        # iterative post-order: digest of (op, operand digests / literals)
+        stack = [root]
+        while stack:
+            i = stack[-1]
+            if i in memo:
+                stack.pop()
+                continue
+            todo = [j for j in d.operands(i) if j not in memo]
+            if todo:
+                stack.extend(todo)
+                continue
+            stack.pop()
+            op, args = d.op[i], d.args[i]
+            if op in ('const', 'in'):
+                parts = [op] + [repr(a) for a in args]
+            elif op == 'powi':
+                parts = [op, memo[args[0]], repr(args[1])]
+            elif op == 'select':
+                parts = [op, repr(args[0])] + [memo[a] for a in args[1:]]
+            else:
+                parts = [str(op)] + [memo[a] for a in args]
+            memo[i] = hashlib.sha256('|'.join(parts).encode()).hexdigest()[:32]
+        return memo[root]
+
+    h = hashlib.sha256()
+    h.update(('epoch=%d' % PLAN_EPOCH).encode())
+    for tag in ('con_out', 'jac_out', 'inst_con_out', 'inst_jac_out'):
+        h.update(('\0%s:' % tag).encode())
+        for r in getattr(prog, tag, ()) or ():
+            h.update(node(r).encode())
+    for tag in ('rows', 'pars', 'h', 'cur_offset', 'adj_offset', 'M', 'C',
+                'n', 'q', 'layout', 'row_start', 'pruned'):
+        h.update(('\0%s=%r' % (tag, getattr(prog, tag, None))).encode())
+    sha = 'p' + h.hexdigest()[:19]
+    try:
+        prog._plan_sha = sha
+    except AttributeError:
+        pass
+    return sha
+
+
+def emitted_sha(prog):
+    """The r01-r04 key: sha of the module the printer emits with default
+    options (only ``tools/migrate_plan_keys.py`` still needs it)."""
     _, meta = emit_module(prog, EmitOptions(), node_blocks=None)
     return meta['sha'][:20]
 
@@ -109,15 +176,34 @@ def options_kwargs(opts):
 
 
 def record(key, entry, path=None):
-    """Merges one entry into the plan file (atomic replace)."""
+    """Merges one entry into the plan file: read-modify-write under an
+    exclusive ``flock`` of ``<path>.lock`` (the ranks of a sharded problem
+    may all replace a refused build at the same moment), atomic replace.  The
+    provenance of a build that replaced one the verification refused
+    (``pinned`` / ``refused``) survives a later :func:`tune` of the same key
+    unless the new entry brings its own."""
     path = path or plan_path() or DEFAULT_FILE
-    plans = dict(_load(path))
-    plans[key] = entry
-    tmp = '%s.%d.tmp' % (path, os.getpid())
-    with open(tmp, 'w') as f:
-        json.dump(plans, f, indent=1, sort_keys=True)
-    os.replace(tmp, path)
-    _cache.pop(path, None)
+    import fcntl
+    with open(path + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            _cache.pop(path, None)
+            plans = dict(_load(path))
+            old = plans.get(key) or {}
+            entry = dict(entry)
+            if 'pinned' in old and 'pinned' not in entry and \
+                    old.get('options') == entry.get('options'):
+                for tag in ('pinned', 'refused'):
+                    if tag in old:
+                        entry.setdefault(tag, old[tag])
+            plans[key] = entry
+            tmp = '%s.%d.tmp' % (path, os.getpid())
+            with open(tmp, 'w') as f:
+                json.dump(plans, f, indent=1, sort_keys=True)
+            os.replace(tmp, path)
+            _cache.pop(path, None)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def _neighbours(seed, low, high):

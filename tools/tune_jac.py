@@ -29,7 +29,9 @@ def parse(spec):
     for item in filter(None, spec.split(',')):
         k, v = item.split('=')
         kw[k] = None if v == 'None' else (
-            v if k in ('ablate', 'con_split', 'small_flush', 'cut') else int(v))
+            v if k in ('ablate', 'con_split', 'small_flush', 'cut', 'order',
+                     'strips')
+            else int(v))
     return EmitOptions(**kw)
 
 
