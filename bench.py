@@ -232,6 +232,53 @@ def other_configs(dev, iters):
     return out
 
 
+def config3_shards(kw, dev, iters, whole_ms):
+    """BASELINE config 4's launches on THIS GPU: one of 2 / 4 / 8 node
+    shards of the benchmark problem (what each GPU of a node launches: its own
+    launch geometry from the launch plans, the global free vector, a node
+    range from the middle), hipEvent-timed like the headline, with the
+    verdict of the build verification of every shard's code object.
+    ``speedup_vs_whole`` = headline launch time / shard launch time: the
+    strong scaling of the evaluation with the outputs left distributed."""
+    import torch
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    from opty_amd.sharded import partition_nodes
+    from examples import problems
+    out = {}
+    base = opty_amd.ConstraintCollocator(device=dev.index, **kw)
+    prog = base._build_program()
+    ncn = base.num_collocation_nodes - 1
+    free = torch.from_numpy(problems.make_free(base.num_free)).to(dev)
+    for world in (2, 4, 8):
+        try:
+            a, b = partition_nodes(ncn, world)[world//2]
+            shard = opty_amd.ConstraintCollocator(
+                device=dev.index, launch_nodes=b - a, **kw)
+            shard._program = prog
+            sh = shard.hip
+            sh.use_torch_stream()
+            scon = torch.empty((prog.M, b - a), dtype=torch.float64,
+                               device=dev)
+            sjac = torch.empty((b - a)*prog.P, dtype=torch.float64,
+                               device=dev)
+            sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a, sjac, a, b,
+                               max(3, iters//4))
+            ms = min(sh.time_eval_shard(hb.EVAL_FUSED, free, scon, b - a,
+                                        sjac, a, b, iters) for _ in range(3))
+            out['shard_1of%d' % world] = dict(
+                nodes=b - a, fused_ms=ms, speedup_vs_whole=whole_ms/ms,
+                fused_pays=not sh.desc.get('fused_loses'),
+                build_check=_build_check(shard))
+            sh.close()
+            del scon, sjac
+        except Exception as exc:         # noqa: the headline must survive
+            out['shard_1of%d' % world] = {'error': '%s: %s' % (
+                type(exc).__name__, str(exc)[:400])}
+        torch.cuda.empty_cache()
+    return out
+
+
 def _build_check(col):
     """What the verification of the code object in use said (every build is
     held to its expression DAG, run as an instruction tape on the GPU, before
@@ -254,16 +301,29 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
                       device=dev)
     jac = torch.empty(hip.nnz, dtype=torch.float64, device=dev)
     res = {}
-    for what, label in ((hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC,
-                                                    'opty_jac'),
-                        (hb.EVAL_FUSED, 'opty_conjac')):
+    # 'opty_conjac' is what OPTY_HIP_EVAL_FUSED / opty_hip_eval_con_jac issue
+    # for this problem: the fused kernel, or -- when the launch plan measured
+    # it slower (opty_hip_desc.fused_loses) -- opty_con followed by opty_jac;
+    # 'opty_conjac_kernel' is the fused kernel itself in that case
+    whats = [(hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC, 'opty_jac'),
+             (hb.EVAL_FUSED, 'opty_conjac')]
+    if hip.desc.get('fused_loses'):
+        whats.append((hb.EVAL_FUSED_KERNEL, 'opty_conjac_kernel'))
+    for what, label in whats:
         hip.time_eval(what, free, con, jac, max(3, iters//4))
         res[label] = hip.time_eval(what, free, con, jac, iters)
     nbytes = 8.0*(col.num_free + col.num_constraints + hip.nnz)
+    serial = res['opty_con'] + res['opty_jac']
     out[name] = dict(
         nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
         fused_algorithmic_bytes=nbytes,
         fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS,
+        fused_pays=not hip.desc.get('fused_loses'),
+        evals_per_s=1e3/res['opty_conjac'],
+        serial_evals_per_s=1e3/serial,
+        # (every launch of this entry reads ONE free vector; the headline
+        # rotates four -- 1-2 % of the bytes of a write stream)
+        free_vectors=1,
         build_check=_build_check(col))
     if name.startswith('config5'):
         # one of eight node shards of the same problem (what each GPU of
@@ -286,7 +346,8 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
                                     jac, a, b, iters) for _ in range(3))
         out[name]['shard_1of8'] = dict(
             nodes=b - a, fused_ms=ms,
-            speedup_vs_whole=res['opty_conjac']/ms)
+            speedup_vs_whole=res['opty_conjac']/ms,
+            build_check=_build_check(shard))
         sh.close()
         del scon
     if name == 'config2_pendulum':
@@ -844,6 +905,10 @@ def main():
         if world == 1:
             extras['other_configs'] = other_configs(dev, max(20,
                                                              args.steps//4))
+            # BASELINE config 4's launches (1/2, 1/4, 1/8 of the benchmark
+            # problem's nodes) on this GPU, next to the headline launch
+            extras['other_configs']['config3_shards'] = config3_shards(
+                kw, dev, max(20, args.steps//4), fused_ms)
             extras['host_path_ms'] = host_path(kw, local_rank)
 
     if verifier is not None:

@@ -55,7 +55,10 @@ enum { OPTY_HIP_BACKWARD_EULER = 0, OPTY_HIP_MIDPOINT = 1 };
 enum { OPTY_HIP_HOST = 0, OPTY_HIP_DEVICE = 1 };
 /* selector for opty_hip_time_eval */
 enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
-       OPTY_HIP_EVAL_FUSED = 3 };
+       OPTY_HIP_EVAL_FUSED = 3,
+       /* the fused kernel itself, whatever opty_hip_desc.fused_loses says
+        * (measurement tools) */
+       OPTY_HIP_EVAL_FUSED_KERNEL = 4 };
 
 #define OPTY_HIP_LAYOUT_COO 0
 #define OPTY_HIP_LAYOUT_CSR 1
@@ -97,7 +100,22 @@ typedef struct opty_hip_desc {
                              instance tails themselves when launched with one
                              workgroup more than the node blocks need (small
                              problems: saves the launch of opty_inst)        */
+    int32_t fused_loses;  /* 1: for this problem and launch size the fused
+                             kernel was MEASURED slower than opty_con followed
+                             by opty_jac (launch plan): opty_hip_eval_con_jac
+                             and OPTY_HIP_EVAL_FUSED issue the two launches.
+                             The reference evaluates the two callbacks
+                             separately in any case
+                             (opty/direct_collocation.py:498-562)            */
 } opty_hip_desc;
+
+/* Version of this header's structs and signatures; opty_hip_abi_version()
+ * returns the one the library was built from.  A client built against another
+ * version must not call the library: the descriptor grew in 5, and
+ * opty_hip_eval_jac_persistent / opty_hip_shard_jac_to_host took their `fresh`
+ * argument in 4. */
+#define OPTY_HIP_ABI_VERSION 5
+int opty_hip_abi_version(void);
 
 /* Loads the code object and allocates the device-side state (known
  * parameters, known trajectories, staging buffers). */
@@ -389,6 +407,61 @@ int opty_hip_host_free(void *ptr);
  * node shard over its own PCIe link ("direct-to-host"). */
 int opty_hip_host_register(void *ptr, size_t bytes);
 int opty_hip_host_unregister(void *ptr);
+/* Device memory for callers without a HIP toolchain of their own (a plain C
+ * host that node-shards a problem: opty_hip_eval_shard and the communicator
+ * calls below take device pointers); `kind`: 0 host->device, 1 device->host,
+ * 2 device->device, synchronous. */
+void *opty_hip_device_alloc(int32_t device, size_t bytes);
+int opty_hip_device_free(void *ptr);
+int opty_hip_memcpy(void *dst, const void *src, size_t bytes, int32_t kind);
+
+/* ---------------------------------------------------------------------------
+ * Several GPUs, one process each: the RCCL side of a node-sharded problem
+ * (BASELINE config 4).  The reference parallelises the node
+ * loop over an OpenMP team (opty/utils.py:524-526); here every rank evaluates
+ * its node range with opty_hip_eval_shard from the global free vector in its
+ * own HBM, and these calls move (i) that vector to every rank and (ii) the
+ * shards to a rank that wants whole vectors -- RCCL point-to-point over xGMI
+ * on the problem handle's stream, issued by this library (librccl is loaded
+ * on first use).  No call here is needed on a single GPU.
+ *
+ * Bring-up: rank 0 calls opty_hip_comm_unique_id and hands the
+ * OPTY_HIP_COMM_ID_BYTES bytes to the other ranks by whatever means the
+ * launcher offers (a file, MPI, a torch.distributed store); every rank then
+ * calls opty_hip_comm_create (collective: it returns when all `world` ranks
+ * have called it). */
+typedef struct opty_hip_comm opty_hip_comm;
+#define OPTY_HIP_COMM_ID_BYTES 128
+int opty_hip_comm_unique_id(void *id_out /* OPTY_HIP_COMM_ID_BYTES bytes */);
+int opty_hip_comm_create(const void *unique_id, int32_t rank, int32_t world,
+                         int32_t device, opty_hip_comm **out);
+int opty_hip_comm_destroy(opty_hip_comm *c);
+int opty_hip_comm_rank(const opty_hip_comm *c);
+int opty_hip_comm_world(const opty_hip_comm *c);
+/* Broadcast of the global free vector (device memory, opty_hip_num_free
+ * doubles on every rank) from rank `root`, ordered on `p`'s stream like an
+ * evaluation.  A no-op in a world of one. */
+int opty_hip_bcast_free(opty_hip_comm *c, opty_hip_problem *p,
+                        double *free_dev, int32_t root);
+/* Gather-v of node shards to rank `root`.  `bounds`: world + 1 ascending
+ * constraint-node boundaries, rank g owns [bounds[g], bounds[g+1]) (shards
+ * may differ in size and may be empty).  Every other rank passes what
+ * opty_hip_eval_shard wrote for its range: `jac_shard` = its (b-a)*P values,
+ * `con_shard` = its dense (M, b-a) block (con_stride = b-a); one grouped
+ * ncclSend each.  The root passes the global vectors of the problem
+ * (opty_hip_num_constraints / opty_hip_nnz doubles): the peers' Jacobian
+ * slices are received IN PLACE (jac[a*P .. b*P), contiguous in the node-major
+ * layout, opty/direct_collocation.py:2885-2887), their constraint blocks into
+ * staging that one strided device copy per peer puts at con[j*(N-1) + a]
+ * (equation-major, :2446).  The root's own shard is copied from `con_shard` /
+ * `jac_shard` unless those are NULL (it evaluated in place: con_stride = N-1,
+ * jac + a*P).  `what`: OPTY_HIP_EVAL_CON, _JAC or _PAIR (both).  The o
+ * instance constraints are not node shards: the root evaluates them itself
+ * (opty_hip_eval_instance).  Asynchronous on `p`'s stream. */
+int opty_hip_gather_v(opty_hip_comm *c, opty_hip_problem *p,
+                      const int64_t *bounds, const double *con_shard,
+                      const double *jac_shard, double *con_global,
+                      double *jac_global, int32_t root, int32_t what);
 
 /* Build verification (no reference counterpart: the reference trusts its C
  * compiler).  Evaluates an instruction tape of a problem's expression DAG

@@ -123,7 +123,12 @@ class EmitOptions(object):
                  fold_instance=None, inline_uniform=None, dear_first=0,
                  cut=None, con_attach=None, forget=0, rotate=None,
                  work_live=None, inline_dynamic=None, order=None, trace=0,
-                 park=0, park_live=215, strips=None):
+                 park=0, park_live=215, strips=None, fused_strips=None,
+                 fused_order=None):
+        # the same two choices for opty_conjac alone (None: as opty_jac's)
+        self.fused_strips = fused_strips
+        assert fused_order in (None, 'block', 'class', 'tail')
+        self.fused_order = fused_order
         # explicit cut of a node-major block (experiments, plan files):
         # ``'96:160;160:348+0:96'`` = two waves, the second one with two
         # strips (boundaries on 16-entry lines; every entry covered once)
@@ -318,7 +323,11 @@ class EmitOptions(object):
                 (' trace=1' if self.trace else '') +
                 (' park=%d/%d' % (self.park, self.park_live)
                  if self.park else '') +
-                ('' if not self.strips else ' strips=%s' % self.strips))
+                ('' if not self.strips else ' strips=%s' % self.strips) +
+                ('' if not self.fused_strips
+                 else ' fused_strips=%s' % self.fused_strips) +
+                ('' if self.fused_order is None
+                 else ' fused_order=%s' % self.fused_order))
 
 
 def _lit(v):
@@ -1092,13 +1101,7 @@ class _ModuleWriter(object):
         groups, each a list of ``(e0, e1)`` strips in evaluation order."""
         P, K = self.p.P, self.o.chunk
         if self.o.strips and self.line_mode() and count is None:
-            groups = [[tuple(int(x) for x in rg.split(':'))
-                       for rg in grp.split('+')]
-                      for grp in self.o.strips.split(';')]
-            cover = sorted(rg for grp in groups for rg in grp)
-            assert cover[0][0] == 0 and cover[-1][1] == P and all(
-                a[1] == b[0] for a, b in zip(cover, cover[1:])) and all(
-                    e0 % 16 == 0 and e1 > e0 for e0, e1 in cover), cover
+            groups = self.explicit_strips(self.o.strips)
             self._auto = (len(groups), len(groups))
             return groups
         unit = 16 if self.line_mode() else K
@@ -1195,6 +1198,18 @@ class _ModuleWriter(object):
         if self._auto_work is not None:
             return [[rg] for rg in self._auto_work]
         return split(self._auto[1])
+
+    def explicit_strips(self, spec):
+        """``'96:160;160:348+0:96'`` -> ``[[(96, 160)], [(160, 348), (0,
+        96)]]``, checked: boundaries on 16-entry lines, every entry once."""
+        P = self.p.P
+        groups = [[tuple(int(x) for x in rg.split(':'))
+                   for rg in grp.split('+')] for grp in spec.split(';')]
+        cover = sorted(rg for grp in groups for rg in grp)
+        assert cover[0][0] == 0 and cover[-1][1] == P and all(
+            a[1] == b[0] for a, b in zip(cover, cover[1:])) and all(
+                e0 % 16 == 0 and e1 > e0 for e0, e1 in cover), cover
+        return groups
 
     def auto_groups(self):
         """``(G_live, G)``: the fewest strips whose waves' estimated live
@@ -1614,7 +1629,7 @@ class _ModuleWriter(object):
 '''
 
     def kernel(self, name, groups, con_of_group, W=1, con_nt=False,
-               inst_lines=None, first_group=0):
+               inst_lines=None, first_group=0, order=None):
         """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
         wave; ``con_of_group[g]`` = constraint rows stored by wave g.  A
         workgroup is ``W`` consecutive groups of one 64-node block: they share
@@ -1638,6 +1653,7 @@ class _ModuleWriter(object):
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
         if W is None:
             if G <= 4 and any(con_of_group) and not self.o.strips and \
+                    not self.o.fused_strips and \
                     self.o.cut != 'work' and self._auto_work is None and \
                     any(e1 > e0 for grp in groups for e0, e1 in grp):
                 # the fused kernel of a small block: its few waves form ONE
@@ -1703,7 +1719,8 @@ class _ModuleWriter(object):
             # biped's Jacobian kernel with 4 work-aware strips: 0.104 ms,
             # with 5: 0.066 ms).
             rot = '(%s + slot/%d)' % (rot, sets)
-        if self.o.order == 'tail' and sets > 1:
+        order = order or self.o.order
+        if order == 'tail' and sets > 1:
             # block by block, then the last ``tail`` blocks of every XCD
             # class by class (sets sorted longest first)
             tail = max(1, RESIDENT_WAVES//(8*max(1, sets - 1)))
@@ -1716,7 +1733,7 @@ class _ModuleWriter(object):
                 'nhead + stail % ntail)*8 + xcd;\n'
                 '    const int grp = (int)(stail < 0 ? slot % {sets} : '
                 'stail/ntail)*{W} + wave;').format(W=W, sets=sets, tail=tail)
-        elif self._class_major():
+        elif order in ('class', 'tail'):
             # strip class by strip class: workgroup set s of every block
             # before set s + 1 of any (the printer sorted the sets longest
             # first); a block's workgroups stay on one XCD
@@ -1774,13 +1791,6 @@ class _ModuleWriter(object):
                           wgs_per_block=sets, lds_bytes=lds_doubles*8,
                           park_rows=park_rows,
                           sha=hashlib.sha256(text.encode()).hexdigest())
-
-    def _class_major(self):
-        # (None = 'block': measured, profiles/r05_wave_timelines.txt -- the
-        # class order pays for the muscle-driven leg, whose long waves are
-        # fewer than the SIMDs, and costs the biped, whose store-only class
-        # then runs alone at the end: a choice for the launch-plan tuner)
-        return self.o.order in ('class', 'tail')
 
     @staticmethod
     def _waves_per_workgroup(slab_rows, ring_rows, lds_per_cu=160*1024):
@@ -2216,6 +2226,8 @@ def emit_module(prog, opts=None, node_blocks=None):
                 fused_jac = groups
     elif opts.fused_groups is not None:
         fused_jac = w.group_ranges(opts.fused_groups)
+    if opts.fused_strips and w.line_mode():
+        fused_jac = w.explicit_strips(opts.fused_strips)
     seeds = dict(jac=len(groups), fused=len(fused_jac),
                  con_waves=len(alone_sets), chunk=opts.chunk,
                  waves=opts.waves, occupancy=opts.occupancy,
@@ -2228,14 +2240,16 @@ def emit_module(prog, opts=None, node_blocks=None):
             return sum(w._strip_cost(e0, e1) for e0, e1 in grp if e1 > e0)
         groups = sorted(groups, key=work, reverse=True)
         fused_jac = sorted(fused_jac, key=work, reverse=True)
-    elif w._class_major():
-        # longest strips first (what the dispatch order of
-        # ``EmitOptions.order`` = 'class' hands out first)
+    else:
+        # longest strips first (what the dispatch orders 'class' / 'tail'
+        # hand out first)
         def work(grp):
             return sum(w._weighted_cost(e0, e1) + STORE_WEIGHT*(e1 - e0)
                        for e0, e1 in grp if e1 > e0)
-        groups = sorted(groups, key=work, reverse=True)
-        fused_jac = sorted(fused_jac, key=work, reverse=True)
+        if opts.order in ('class', 'tail'):
+            groups = sorted(groups, key=work, reverse=True)
+        if (opts.fused_order or opts.order) in ('class', 'tail'):
+            fused_jac = sorted(fused_jac, key=work, reverse=True)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
     # waves ride in the shadow of the store-bound Jacobian waves.  Where the
@@ -2280,7 +2294,8 @@ def emit_module(prog, opts=None, node_blocks=None):
         src, meta = w.kernel(
             name, grp, cons, wpw, nt, inst_lines=folded,
             first_group=len(fused_jac) if (opts.dear_first and
-                                           key == 'conjac') else 0)
+                                           key == 'conjac') else 0,
+            order=opts.fused_order if key == 'conjac' else None)
         parts += [src, '']
         kernels[key] = meta
     if prog.inst_con_out:

@@ -1195,7 +1195,20 @@ class ConstraintCollocator(object):
             device=self._device,
             layout={'coo': 0, 'csr': 1,
                     'varying_first': 2}[self._jacobian_layout],
-            inst_folded=int(meta.get('inst_folded', False)))
+            inst_folded=int(meta.get('inst_folded', False)),
+            fused_loses=self._fused_loses())
+
+    def _fused_loses(self):
+        """1 when the launch plan of this problem and launch size measured
+        the fused kernel slower than ``opty_con`` + ``opty_jac`` (``"fused_
+        pays": false``): ``opty_hip_eval_con_jac`` / ``EVAL_FUSED`` then issue
+        those two launches."""
+        if self._emit_options is not None:
+            return 0
+        from . import launch_plan
+        entry = launch_plan.lookup_entry(self._build_program(),
+                                         self._launch_blocks())
+        return int(bool(entry) and entry.get('fused_pays') is False)
 
     def _known_trajectory_array(self, free):
         vals = []

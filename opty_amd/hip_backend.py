@@ -28,10 +28,12 @@ LIB_PATH = os.path.join(_PKG, 'libopty_hip.so')
 DEFAULT_CACHE = os.path.join(_PKG, '_cache')
 ARCH = 'gfx950'
 
+#: OPTY_HIP_ABI_VERSION of include/opty_hip.h these bindings were written for
+ABI_VERSION = 5
 HOST, DEVICE = 0, 1
 #: hipStreamLegacy: the null / legacy default stream (torch's default)
 STREAM_LEGACY = 1
-EVAL_CON, EVAL_JAC, EVAL_PAIR, EVAL_FUSED = 0, 1, 2, 3
+EVAL_CON, EVAL_JAC, EVAL_PAIR, EVAL_FUSED, EVAL_FUSED_KERNEL = 0, 1, 2, 3, 4
 
 
 class HipBackendError(RuntimeError):
@@ -269,7 +271,7 @@ class _Desc(ctypes.Structure):
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device', 'fused_waves_per_wg',
-            'con_waves_per_wg', 'layout', 'inst_folded')]
+            'con_waves_per_wg', 'layout', 'inst_folded', 'fused_loses')]
 
 
 class _MatDesc(ctypes.Structure):
@@ -355,6 +357,22 @@ _SIGNATURES = {
     'opty_hip_host_free': (ctypes.c_int, [_P]),
     'opty_hip_tape_run': (ctypes.c_int, [ctypes.c_int32, _P, ctypes.c_int64,
                                          _P, ctypes.c_int64, ctypes.c_int64]),
+    'opty_hip_device_alloc': (ctypes.c_void_p, [ctypes.c_int32,
+                                                 ctypes.c_size_t]),
+    'opty_hip_device_free': (ctypes.c_int, [_P]),
+    'opty_hip_memcpy': (ctypes.c_int, [_P, _P, ctypes.c_size_t,
+                                       ctypes.c_int32]),
+    'opty_hip_comm_unique_id': (ctypes.c_int, [_P]),
+    'opty_hip_comm_create': (ctypes.c_int, [_P, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.POINTER(_P)]),
+    'opty_hip_comm_destroy': (ctypes.c_int, [_P]),
+    'opty_hip_comm_rank': (ctypes.c_int, [_P]),
+    'opty_hip_comm_world': (ctypes.c_int, [_P]),
+    'opty_hip_bcast_free': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
+    'opty_hip_gather_v': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P,
+                                         ctypes.c_int32, ctypes.c_int32]),
+    'opty_hip_abi_version': (ctypes.c_int, []),
     'opty_hip_device_count': (ctypes.c_int, []),
     'opty_hip_last_error': (ctypes.c_char_p, []),
 }
@@ -382,6 +400,19 @@ def load_library():
                     '-c "import __graft_entry__ as g; g.build()"`'
                     % (LIB_PATH, err))
         lib = ctypes.CDLL(LIB_PATH)
+        # the bindings below mirror ONE version of include/opty_hip.h: a
+        # library built from another one would read the descriptor / the
+        # trailing arguments wrongly without any error
+        try:
+            version = lib.opty_hip_abi_version()
+        except AttributeError:
+            version = None
+        if version != ABI_VERSION:
+            raise HipBackendError(
+                '%s implements version %s of the C ABI, these bindings '
+                'version %d (include/opty_hip.h: OPTY_HIP_ABI_VERSION): '
+                'rebuild it -- `python -c "import __graft_entry__ as g; '
+                'g.build()"`' % (LIB_PATH, version, ABI_VERSION))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res
@@ -652,6 +683,71 @@ class HipProblem(object):
             self._h, what, _ptr(free), _ptr(con), _ptr(jac), iters,
             ctypes.byref(ms)))
         return ms.value
+
+
+class HipComm(object):
+    """One ``opty_hip_comm``: this process's rank in an RCCL communicator
+    of one-process-per-GPU ranks (``include/opty_hip.h``).  The collective
+    calls go through the C ABI -- grouped ``ncclSend`` / ``ncclRecv`` issued by
+    the library on the problem handle's stream -- not through a PyTorch
+    process group."""
+
+    ID_BYTES = 128
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self._lib = load_library()
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError('unique_id must be %d bytes' % self.ID_BYTES)
+        self._h = _P()
+        buf = ctypes.create_string_buffer(bytes(unique_id), self.ID_BYTES)
+        _check(self._lib.opty_hip_comm_create(
+            ctypes.addressof(buf), int(rank), int(world), int(device),
+            ctypes.byref(self._h)))
+        self.rank, self.world, self.device = int(rank), int(world), device
+
+    @staticmethod
+    def unique_id():
+        """``ncclGetUniqueId`` as bytes (one rank calls this and hands the
+        result to the others)."""
+        buf = ctypes.create_string_buffer(HipComm.ID_BYTES)
+        _check(load_library().opty_hip_comm_unique_id(ctypes.addressof(buf)))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None, device=0):
+        """Bootstraps the communicator over an initialised
+        ``torch.distributed`` group of any backend (the 128-byte id travels
+        as an object broadcast); the data path afterwards is this library's
+        own RCCL communicator."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0)
+                                   if group is not None else 0, group=group)
+        return cls(box[0], rank, world, device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.opty_hip_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def bcast_free(self, hip, free, root=0):
+        """``opty_hip_bcast_free``: the global free vector (device tensor /
+        pointer) from ``root`` to every rank, on ``hip``'s stream."""
+        _check(self._lib.opty_hip_bcast_free(self._h, hip._h, _ptr(free),
+                                             int(root)))
+
+    def gather_v(self, hip, bounds, con_shard, jac_shard, con_global,
+                 jac_global, root=0, what=EVAL_PAIR):
+        """``opty_hip_gather_v``: node shards to ``root`` (Jacobian slices
+        in place, constraint blocks through one strided copy per peer)."""
+        b = np.ascontiguousarray(bounds, dtype=np.int64)
+        assert len(b) == self.world + 1
+        _check(self._lib.opty_hip_gather_v(
+            self._h, hip._h, _ptr(b), _ptr(con_shard), _ptr(jac_shard),
+            _ptr(con_global), _ptr(jac_global), int(root), int(what)))
 
 
 class HipMatrix(object):

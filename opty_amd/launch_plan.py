@@ -212,9 +212,59 @@ def _neighbours(seed, low, high):
     return sorted(g for g in out if low <= g <= high)
 
 
+#: LDS of one workgroup up to which a CU holds four of them (the generated
+#: kernels run one wave per SIMD at their register footprint)
+LDS_FOUR_PER_CU = 40*1024
+
+
+def _merged_cuts(prog, seed, g):
+    """Cuts of an arithmetic-bound block with FEWER long strips than the
+    register file allows without help: the work-aware cut under a relaxed
+    bound on a strip's live values, the waves that exceed the registers
+    planned with LDS parking (``EmitOptions.park``).  ``[(tag, fused_strips
+    spec)]``: every strip a wave of its own, and the short strips merged into
+    one wave."""
+    from .codegen.emit_hip import _ModuleWriter
+    out, seen = [], set()
+    nunits = prog.P//16
+    if not 2 < nunits <= 128:
+        return out
+    chunk = seed.get('chunk', 32)
+    w = _ModuleWriter(prog, EmitOptions(cut='work', work_live=400,
+                                        chunk=chunk))
+    for S in range(max(2, g['fused'] - 2), g['fused'] + 1):
+        strips = w._work_cut(S, 16, nunits)
+        if not strips:
+            continue
+        cost = [w._weighted_cost(e0, e1) for e0, e1 in strips]
+        long_ = [k for k in range(len(strips))
+                 if cost[k] >= 0.25*max(cost)]
+        short = [k for k in range(len(strips)) if k not in long_]
+        spec = ';'.join('%d:%d' % strips[k] for k in range(len(strips)))
+        if spec not in seen:
+            seen.add(spec)
+            out.append(('merge%d' % S, spec))
+        if len(short) > 1:
+            # (the strip that ends the block wraps into entries 0..14: last)
+            runs = []
+            for k in sorted(short):
+                if runs and runs[-1][1] == strips[k][0]:
+                    runs[-1] = (runs[-1][0], strips[k][1])
+                else:
+                    runs.append(strips[k])
+            runs.sort(key=lambda rg: (rg[1] != prog.P, rg[0]))
+            spec = ';'.join(['%d:%d' % strips[k] for k in long_] +
+                            ['+'.join('%d:%d' % rg for rg in runs)])
+            if spec not in seen:
+                seen.add(spec)
+                out.append(('merge%d+' % S, spec))
+    return out
+
+
 def candidates(prog, node_blocks):
     """Printer-option variants worth timing around the seed geometry:
-    ``[(label, options kwargs)]``, the seed first."""
+    ``[(label, options kwargs)]``, the seed first.  Labels ``fused...`` /
+    ``jac...`` only compete for that kernel."""
     _, meta = emit_module(prog, EmitOptions(), node_blocks=node_blocks)
     g = meta['geometry']
     seed = dict(groups=g['jac'], fused_groups=g['fused'])
@@ -235,10 +285,15 @@ def candidates(prog, node_blocks):
     unit = 16
     top = max(1, min(32, prog.P//unit))
     low = max(1, -(-3*(g['live'] or 1)//5))
-    for f in _neighbours(g['fused'], low, top):
-        if f != g['fused']:
-            out.append(('fused=%d' % f, dict(seed, fused_groups=f)))
-    for j in _neighbours(g['jac'], low, top):
+    fused_counts = [f for f in _neighbours(g['fused'], low, top)
+                    if f != g['fused']]
+    for f in fused_counts:
+        out.append(('fused=%d' % f, dict(seed, fused_groups=f)))
+    # the Jacobian-only kernel competes with the fused kernel's counts too
+    # (r04: the 24-link opty_jac with its own 32 strips was slower than the
+    # fused kernel that does strictly more with 20)
+    jac_counts = _neighbours(g['jac'], low, top) + [g['fused']] + fused_counts
+    for j in sorted(set(jac_counts)):
         if j != g['jac']:
             out.append(('jac=%d' % j, dict(seed, groups=j)))
     if g['chunk'] == 32 and not g['occupancy']:
@@ -247,6 +302,31 @@ def candidates(prog, node_blocks):
         # slabs (50-state systems) and short launches (node shards) may prefer
         out.append(('c16', dict(seed, chunk=16)))
         out.append(('c16w4', dict(seed, chunk=16, waves=4)))
+    if g.get('cut') == 'work' or meta.get('con_attached'):
+        # blocks bound by their arithmetic (unequal waves, one per SIMD): the
+        # dispatch order of a launch's workgroups, and cuts with fewer long
+        # strips whose waves park values in LDS
+        for order in ('class', 'tail'):
+            out.append(('jac:%s' % order, dict(seed, order=order)))
+            out.append(('fused:%s' % order, dict(seed, fused_order=order)))
+        shapes = [('', {})]
+        if g['chunk'] == 32 and not g['occupancy']:
+            shapes.append(('c16:', dict(chunk=16)))     # 17 KB less ring
+        for pre, shape in shapes:
+            base = dict(seed, **shape)
+            for tag, spec in _merged_cuts(prog, base, g):
+                for live in (235, 225):
+                    kw = dict(base, fused_strips=spec, park=48,
+                              park_live=live)
+                    _, m = emit_module(prog, EmitOptions(**kw),
+                                       node_blocks=node_blocks)
+                    if m['kernels']['conjac']['lds_bytes'] > \
+                            LDS_FOUR_PER_CU or not m.get('plans'):
+                        continue    # would cost resident waves / no parking
+                    out.append(('fused:%s%s/%d' % (pre, tag, live), kw))
+                    out.append(('fused:%s%s/%d:class' % (pre, tag, live),
+                                dict(kw, fused_order='class')))
+                    break
     return out, g
 
 
@@ -310,18 +390,22 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
         h.use_torch_stream()
         handles.append(h)
     times = {k: [[] for _ in built] for k in ('fused', 'jac')}
-    sel = {'fused': hb.EVAL_FUSED, 'jac': hb.EVAL_JAC}
+    con_ms = []
+    sel = {'fused': hb.EVAL_FUSED_KERNEL, 'jac': hb.EVAL_JAC}
     # clock ramp
     for _ in range(3):
         handles[0].time_eval_shard(hb.EVAL_FUSED, free, con, nodes, jac, a, b,
                                    iters)
     for _ in range(rounds):
+        # (opty_con does not depend on the geometry of the Jacobian waves)
+        con_ms.append(handles[0].time_eval_shard(
+            hb.EVAL_CON, free, con, nodes, jac, a, b, iters))
         for k, h in enumerate(handles):
             for what in ('fused', 'jac'):
                 label = built[k][0]
-                if what == 'fused' and label.startswith('jac='):
+                if what == 'fused' and label.startswith('jac'):
                     continue
-                if what == 'jac' and label.startswith('fused='):
+                if what == 'jac' and label.startswith('fused'):
                     continue
                 if {'fused': 'opty_conjac', 'jac': 'opty_jac'}[what] in \
                         built[k][4]:
@@ -366,14 +450,27 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
                 for k, (label, kw, _, _, _) in enumerate(built)
                 if times['jac'][k] and shape(kw) == shape(options)]
         if same:
-            options['groups'] = min(same, key=lambda t: t[0])[1]['groups']
+            # what only the Jacobian kernel reads: its strip count and the
+            # dispatch order of its workgroups
+            jac_ms, jac_kw = min(same, key=lambda t: t[0])
+            for tag in ('groups', 'order'):
+                options.pop(tag, None)
+                if tag in jac_kw:
+                    options[tag] = jac_kw[tag]
+            best['jac'] = (jac_ms, 'jac', jac_kw)
     else:
         # small blocks: the only choice is how the tile is flushed; the fused
         # kernel decides
         options = dict(small_flush='chunk') \
             if best['fused'][1] == 'chunk' else {}
     sha = problem_sha(prog)
-    entry = dict(options=options,
+    measured['con'] = float(np.median(con_ms))
+    # does ONE fused launch beat the two it replaces?  (opty_hip_desc.
+    # fused_loses: opty_hip_eval_con_jac / EVAL_FUSED issue opty_con and
+    # opty_jac when it does not -- by more than the resolution of the timer)
+    fused_pays = best['fused'][0] <= \
+        (best['jac'][0] + measured['con'])*1.01 + 3e-4
+    entry = dict(options=options, fused_pays=bool(fused_pays),
                  seed=dict(jac=geo['jac'], fused=geo['fused']),
                  measured_ms=measured, nodes=nodes,
                  device=torch.cuda.get_device_name(dev), problem_sha=sha)

@@ -233,8 +233,13 @@ class ShardedCollocator(object):
                  known_parameter_map={}, known_trajectory_map={},
                  instance_constraints=None, rank=None, world_size=None,
                  group=None, device=None, evaluator=None, block_shape=None,
-                 instance_evaluator=None, **kwargs):
+                 instance_evaluator=None, comm=None, **kwargs):
         import torch
+        #: ``hip_backend.HipComm`` (or None): when given -- and the HIP
+        #: evaluator is in use -- :meth:`broadcast_free` and :meth:`gather` go
+        #: through the C ABI's own RCCL communicator (``opty_hip_bcast_free``
+        #: / ``opty_hip_gather_v``) instead of ``torch.distributed``
+        self.comm = comm
         if kwargs.get('jacobian_layout', 'coo') != 'coo':
             raise NotImplementedError(
                 'only the node-major layout is node-sharded: a shard of the '
@@ -489,6 +494,10 @@ class ShardedCollocator(object):
         """RCCL broadcast of the global free vector from rank ``src`` (18 MB
         for config 4).  The alternative with ``free`` on the host: every rank
         loads it over its own PCIe link from a :class:`SharedHostVector`."""
+        if self.comm is not None and self._hip_mode:
+            self._use_stream()
+            self.comm.bcast_free(self.collocator.hip, free, src)
+            return free
         import torch.distributed as dist
         dist.broadcast(free, src, group=self.group)
         return free

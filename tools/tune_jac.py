@@ -30,7 +30,7 @@ def parse(spec):
         k, v = item.split('=')
         kw[k] = None if v == 'None' else (
             v if k in ('ablate', 'con_split', 'small_flush', 'cut', 'order',
-                     'strips')
+                     'strips', 'fused_strips', 'fused_order')
             else int(v))
     return EmitOptions(**kw)
 
