@@ -387,8 +387,9 @@ def host_path(kw, dev_index, reps=7):
     from opty_amd import hip_backend as hb
     from examples import problems
 
-    def med(fn, frees):
-        fn(frees[0])
+    def med(fn, frees, warm=1):
+        for k in range(warm):
+            fn(frees[k % len(frees)])
         ts = []
         for k in range(reps):
             t0 = time.perf_counter()
@@ -414,9 +415,19 @@ def host_path(kw, dev_index, reps=7):
             # ... of which only the distinct expressions cross PCIe
             out['moved_entries_per_block'] = len(unique)
             out['host_threads'] = hb.host_threads()
-        out['jac' + label] = med(col.generate_jacobian_function(), frees)
+        # (the default layout's host scatter verifies its thread placement
+        # over its first calls -- opty_hip.cpp ScatterPool::feedback; they are
+        # warm-up)
+        out['jac' + label] = med(col.generate_jacobian_function(), frees,
+                                 warm=8 if not label else 2)
         out['nnz' + label] = col.hip.nnz
         col.hip.close()
+    # regression guard: the reference-ordered default layout
+    # must stay within 15 % of the scatter-free opt-in layout, which sits on
+    # the PCIe link
+    out['jac_guard'] = {
+        'ok': bool(out['jac'] <= 1.15*out['jac_varying_first']),
+        'ratio': out['jac']/out['jac_varying_first'], 'limit': 1.15}
     out['pair_evals_per_s'] = 1e3/(out['con'] + out['jac'])
     out['pair_pruned_evals_per_s'] = 1e3/(out['con'] + out['jac_pruned'])
     # the reference's triplets in another order (opt-in): the entries that

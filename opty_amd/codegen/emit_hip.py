@@ -124,7 +124,14 @@ class EmitOptions(object):
                  cut=None, con_attach=None, forget=0, rotate=None,
                  work_live=None, inline_dynamic=None, order=None, trace=0,
                  park=0, park_live=215, strips=None, fused_strips=None,
-                 fused_order=None):
+                 fused_order=None, deterministic=0):
+        # 1: every wave prints the same operations for the same DAG node:
+        # sin / cos of an argument whose other half exists anywhere in the
+        # DAG always come from one ``sincos`` (not from ``sin`` alone in the
+        # waves that happen to need only one of the two).  Together with
+        # ``-ffp-contract=off`` (hip_backend.DETERMINISTIC_FLAGS) a node's
+        # values are bit-identical in every launch geometry
+        self.deterministic = int(deterministic)
         # the same two choices for opty_conjac alone (None: as opty_jac's)
         self.fused_strips = fused_strips
         assert fused_order in (None, 'block', 'class', 'tail')
@@ -327,7 +334,8 @@ class EmitOptions(object):
                 ('' if not self.fused_strips
                  else ' fused_strips=%s' % self.fused_strips) +
                 ('' if self.fused_order is None
-                 else ' fused_order=%s' % self.fused_order))
+                 else ' fused_order=%s' % self.fused_order) +
+                (' deterministic=1' if self.deterministic else ''))
 
 
 def _lit(v):
@@ -350,8 +358,9 @@ class _Body(object):
     scope (``new_scope``), computed temporaries are emitted once.
     """
 
-    def __init__(self, dag, needed, leaf, fast_trig=True):
+    def __init__(self, dag, needed, leaf, fast_trig=True, deterministic=False):
         self.dag = dag
+        self.deterministic = bool(deterministic)
         self.trig = 'opty_' if fast_trig else ''
         self.lines = []
         self.done = {}
@@ -484,6 +493,18 @@ class _Body(object):
         elif op in ('sin', 'cos'):
             other = 'cos' if op == 'sin' else 'sin'
             j = d._memo.get((other, a))
+            if self.deterministic and j is not None:
+                # one form in every wave: the pair, whether this wave needs
+                # the other half or not (it is dead code then)
+                tag = len(self.lines)
+                sn, cn = 'sc%d_%ds' % (i, tag), 'sc%d_%dc' % (i, tag)
+                self.lines.append('double %s, %s; %ssincos(%s, &%s, &%s);'
+                                  % (sn, cn, self.trig, r(a[0]), sn, cn))
+                self.done[i] = sn if op == 'sin' else cn
+                if j in self.needed and not self._have(j) and \
+                        self.leaf(j) is None:
+                    self.done[j] = cn if op == 'sin' else sn
+                return
             if (j is not None and j in self.needed and not self._have(j)
                     and self.leaf(j) is None):
                 s_id, c_id = (i, j) if op == 'sin' else (j, i)
@@ -1286,7 +1307,8 @@ class _ModuleWriter(object):
                 return 'uni_c[%d]' % self._slot(i)
             return None
 
-        body = _Body(d, needed, leaf, self.o.fast_trig)
+        body = _Body(d, needed, leaf, self.o.fast_trig,
+                     self.o.deterministic)
         # LDS parking: the wave is planned as a whole (constraint rows
         # included) when it is worth it -- its temporaries in memory order
         # would not fit the registers
@@ -1388,7 +1410,17 @@ class _ModuleWriter(object):
                 i, pair = ev[1], ev[2]
                 for j in d.operands(i):
                     operand(j)
-                if d.op[i] in ('sin', 'cos'):
+                if d.op[i] in ('sin', 'cos') and body.deterministic:
+                    body._emit_node(i)
+                    if pair is None:
+                        # (the plan did not ask for the other half here: it
+                        # is computed again where it is needed)
+                        other = 'cos' if d.op[i] == 'sin' else 'sin'
+                        j = d._memo.get((other, d.args[i]))
+                        if j is not None and j in body.done and \
+                                body.done[j].startswith('sc%d_' % i):
+                            del body.done[j]
+                elif d.op[i] in ('sin', 'cos'):
                     a = body.ref(d.args[i][0])
                     if pair is not None:
                         s_id, c_id = (i, pair) if d.op[i] == 'sin' \
@@ -1834,7 +1866,7 @@ class _ModuleWriter(object):
         for b in range(nparts):
             part = slots[b*len(slots)//nparts:(b + 1)*len(slots)//nparts]
             body = _Body(d, set(d.reachable([i for i, _ in part])), leaf,
-                         self.o.fast_trig)
+                         self.o.fast_trig, self.o.deterministic)
             for i, s in part:
                 ref = body.emit(i)
                 body.lines.append('uni_w[%d] = %s;' % (s, ref))
@@ -1861,7 +1893,8 @@ class _ModuleWriter(object):
                 return self._scalar_source(i)
             return None
 
-        body = _Body(d, needed, leaf, self.o.fast_trig)
+        body = _Body(d, needed, leaf, self.o.fast_trig,
+                     self.o.deterministic)
         for k, node in enumerate(p.inst_con_out):
             ref = body.emit(node)
             body.lines.append('if (con) con[%dLL*con_stride + %d] = %s;'

@@ -308,7 +308,8 @@ public:
         node_ = node;
         cpus_ = set;
         have_cpus_ = true;
-        resize(threads());
+        want_threads_ = std::max(want_threads_, threads());
+        resize(want_threads_);
     }
 
     void resize(int n) {
@@ -320,10 +321,123 @@ public:
         // the epoch the new workers have seen is fixed HERE, by the thread
         // that also starts the jobs: a worker that read it on its own could
         // start late, after the first job was posted, and sleep through it
+        // never more placed workers than the node has physical cores of
+        // ours: two on one core share its load / store bandwidth, and a
+        // handful of well-placed threads beat sixteen badly placed ones
+        if (have_cpus_ && !cores_.empty()) {
+            const long long share = std::max<long long>(
+                1, (long long)cores_.size()/local_ranks().second);
+            n = (int)std::min<long long>(n, share);
+        }
         const unsigned long long seen = epoch_;
+        worker_cpu_.assign((size_t)n, -1);
         for (int t = 0; t < n; ++t)
             workers_.emplace_back([this, t, n, seen] { work(t, n, seen); });
     }
+
+    // -- placement that is verified, not assumed ------------------------------
+    // The NUMA node of the caller's vector comes from get_mempolicy, which a
+    // container's seccomp profile may refuse and which says nothing about how
+    // the box's fabric treats that node: on one box of round 4 the default
+    // placement finished the scatter 3.4 ms after the last DMA chunk (7.95 ms
+    // per Jacobian, against 4.57 ms on another).  So the pool measures: a
+    // call whose scatter ends late (`lag`: time after the last chunk landed)
+    // twice in a row makes the pool try every NUMA node that has CPUs of ours
+    // -- and the unplaced pool -- for one call each, and keep the best for
+    // this vector.
+    void target(const void *vector, int policy_node) {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
+        if (vector != vector_) {
+            vector_ = vector;
+            cand_.clear();
+            exploring_ = -1;
+            settled_ = false;
+            bad_streak_ = 0;
+            want_threads_ = std::max(want_threads_, threads());
+        }
+        if (exploring_ < 0 && !settled_) set_numa_node(policy_node);
+    }
+
+    void feedback(double dma_ms, double lag_ms) {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
+        static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+        static const bool off = [] {
+            const char *e = getenv("OPTY_HIP_HOST_PLACEMENT");
+            return e && strcmp(e, "fixed") == 0;
+        }();
+        if (settled_ || off) return;
+        const bool bad = lag_ms > std::max(0.6, 0.15*dma_ms);
+        if (exploring_ < 0) {
+            if (!bad) { bad_streak_ = 0; return; }
+            if (++bad_streak_ < 2) return;
+            cand_.clear();
+            cand_.push_back({node_, lag_ms});
+            for (int node = 0; node < 64; ++node) {
+                char path[96];
+                snprintf(path, sizeof path,
+                         "/sys/devices/system/node/node%d/cpulist", node);
+                if (node != node_ && access(path, R_OK) == 0)
+                    cand_.push_back({node, -1.0});
+            }
+            if (node_ >= 0) cand_.push_back({-1, -1.0});   // unplaced
+            exploring_ = 1;
+        } else {
+            cand_[(size_t)exploring_].second = lag_ms;
+            ++exploring_;
+        }
+        while (exploring_ < (int)cand_.size()) {
+            if (place(cand_[(size_t)exploring_].first)) return;
+            cand_[(size_t)exploring_].second = 1e9;     // no CPUs of ours there
+            ++exploring_;
+        }
+        size_t best = 0;
+        for (size_t k = 1; k < cand_.size(); ++k)
+            if (cand_[k].second >= 0 && cand_[k].second < cand_[best].second)
+                best = k;
+        place(cand_[best].first);
+        settled_ = true;
+        exploring_ = -1;
+        if (trace) {
+            fprintf(stderr, "opty_hip: scatter placement settled on NUMA node "
+                    "%d after measuring:", cand_[best].first);
+            for (auto &c : cand_)
+                fprintf(stderr, " node %d: +%.2f ms;", c.first, c.second);
+            fprintf(stderr, "\n");
+        }
+    }
+
+    void request_threads(int n) {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
+        want_threads_ = n;
+        resize(n);
+    }
+
+    // "worker -> cpu" of the last job (OPTY_HIP_TRACE)
+    void report(FILE *f) const {
+        fprintf(f, "opty_hip: scatter workers (node %d):", node_);
+        for (size_t t = 0; t < worker_cpu_.size(); ++t)
+            fprintf(f, " %zu->cpu%d", t, worker_cpu_[t]);
+        fprintf(f, "\n");
+    }
+
+private:
+    // workers on `node` (-1: unplaced, the creating thread's mask); false
+    // when that node has no CPUs of ours
+    bool place(int node) {
+        if (node < 0) {
+            node_ = -1;
+            have_cpus_ = false;
+            cores_.clear();
+            resize(std::max(want_threads_, 1));
+            return true;
+        }
+        const int before = node_;
+        node_ = -2;                 // force set_numa_node to act
+        set_numa_node(node);
+        if (node_ != node) { node_ = before; return false; }
+        return true;
+    }
+public:
 
     // The caller publishes chunks [0, c) as landed with ready(c) and finally
     // waits for the workers.
@@ -413,6 +527,7 @@ private:
                 seen = epoch_;
             }
             const Job j = job_;
+            if (t < (int)worker_cpu_.size()) worker_cpu_[(size_t)t] = sched_getcpu();
             for (int c = 0; c < j.chunks; ++c) {
                 // a chunk lands every ~0.3 ms: spin briefly, then give the
                 // core away between polls
@@ -483,6 +598,11 @@ private:
     bool have_cpus_ = false;
     cpu_set_t cpus_;
     std::vector<int> cores_;     // one CPU per physical core of that node
+    std::vector<int> worker_cpu_;    // where each worker ran its last job
+    const void *vector_ = nullptr;   // the vector the placement was chosen for
+    std::vector<std::pair<int, double>> cand_;  // (node, lag) while exploring
+    int exploring_ = -1, bad_streak_ = 0, want_threads_ = 0;
+    bool settled_ = false;
     std::vector<std::thread> workers_;
     std::mutex m_;
     std::recursive_mutex busy_;   // a job, or a restart of the workers
@@ -1730,7 +1850,7 @@ int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
 int opty_hip_set_host_threads(int32_t count) {
     if (count < 0) return fail("thread count must be >= 0");
     ScatterPool &pool = ScatterPool::instance();
-    pool.resize(count == 0 ? ScatterPool::default_threads() : count);
+    pool.request_threads(count == 0 ? ScatterPool::default_threads() : count);
     return 0;
 }
 
@@ -1944,7 +2064,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         }
     }
     ScatterPool &pool = ScatterPool::instance();
-    pool.set_numa_node(host_numa_node(h_blocks));
+    pool.target(h_blocks, host_numa_node(h_blocks));
     ScatterPool::Job job;
     job.packed = p->h_packed;
     job.dense = h_blocks;
@@ -1964,7 +2084,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         return std::chrono::duration<double, std::milli>(
             std::chrono::steady_clock::now().time_since_epoch()).count();
     };
-    const double t0 = trace ? now() : 0.0;
+    const double t0 = now();
     pool.start(job);
     int rc = 0;
     double t_first = 0.0;
@@ -1977,15 +2097,21 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         if (trace && c == 0) t_first = now();
         pool.ready(c + 1);      // also after a failure: the workers must end
     }
-    const double t_dma = trace ? now() : 0.0;
+    const double t_dma = now();
     pool.wait();
-    if (trace)
+    const double t_end = now();
+    if (trace) {
         fprintf(stderr, "opty_hip: %lld nodes x %d entries in %d chunks: "
                 "first chunk landed +%.2f ms, last +%.2f ms, scatter done "
                 "+%.2f ms; %d threads on NUMA node %d (vector on node %d), "
                 "caller on cpu %d\n", count, V, chunks, t_first - t0,
-                t_dma - t0, now() - t0, pool.threads(), pool.numa_node(),
+                t_dma - t0, t_end - t0, pool.threads(), pool.numa_node(),
                 host_numa_node(h_blocks), sched_getcpu());
+        pool.report(stderr);
+    }
+    // late scatter -> the pool looks for a better placement (one candidate
+    // per call, then keeps the best for this vector)
+    if (rc == 0) pool.feedback(t_dma - t0, t_end - t_dma);
     return rc;
 }
 

@@ -75,7 +75,17 @@ class ConstraintCollocator(object):
                  integration_method='backward euler', parallel=False,
                  show_compile_output=False, backend='hip', device=0,
                  emit_options=None, prune_zeros=False,
-                 jacobian_layout='coo', launch_nodes=None):
+                 jacobian_layout='coo', launch_nodes=None,
+                 deterministic=False):
+        # opt-in: values that do not depend on the launch a node is evaluated
+        # in (node window, shard, strip count, fused or separate kernels) --
+        # bit for bit, as the reference's are (one scalar function per node,
+        # opty/utils.py:483-494).  The kernels are built without FMA
+        # contraction and with one fixed form of every sin / cos pair
+        # (``EmitOptions.deterministic``), so that every entry is the same
+        # sequence of individually rounded operations whichever wave
+        # evaluates it.
+        self._deterministic = bool(deterministic)
         self._prune_zeros = bool(prune_zeros)
         # constraint nodes one launch covers (a node shard evaluates fewer
         # than N - 1): picks the kernels' strip count for small launches
@@ -553,7 +563,21 @@ class ConstraintCollocator(object):
             from . import launch_plan
             opts = launch_plan.lookup(self._build_program(),
                                       self._launch_blocks()) or EmitOptions()
+        if self._deterministic and not opts.deterministic:
+            import copy
+            opts = copy.copy(opts)
+            opts.deterministic = 1
         return opts
+
+    def _compile(self, source, opt_level=None, extra_flags=()):
+        """``hipcc --genco`` of one of this problem's modules (a
+        ``deterministic`` collocator's without FMA contraction)."""
+        if self._deterministic:
+            extra_flags = tuple(extra_flags) + hb.DETERMINISTIC_FLAGS
+        return hb.compile_module(source, self.tmp_dir,
+                                 self.show_compile_output,
+                                 opt_level=opt_level,
+                                 extra_flags=tuple(extra_flags))
 
     def _emit(self, opts):
         return emit_module(self._build_program(), opts,
@@ -573,17 +597,14 @@ class ConstraintCollocator(object):
             # (_verified_alternative): reproduced exactly as recorded
             opts, how = pinned
             source, meta = self._emit(opts)
-            hsaco = hb.compile_module(
-                source, self.tmp_dir, self.show_compile_output,
-                opt_level=how.get('opt_level'),
+            hsaco = self._compile(
+                source, opt_level=how.get('opt_level'),
                 extra_flags=tuple(how.get('extra_flags', ())))
             self._built_source, self._built_options = source, opts
             return hsaco, meta
         opts = self._printer_options()
         source, meta = self._emit(opts)
-        hsaco = hb.compile_module(source, self.tmp_dir,
-                                  self.show_compile_output,
-                                  opt_level=opt_level)
+        hsaco = self._compile(source, opt_level=opt_level)
         self._built_source, self._built_options = source, opts
         if self._emit_options is not None:
             # the caller fixed the geometry: it is built as asked, but never
@@ -636,10 +657,10 @@ class ConstraintCollocator(object):
                                              else 0)
                 trial.fused_groups = geo['fused'] + (
                     d if 'opty_conjac' in best[2] else 0)
+            if self._deterministic:
+                trial.deterministic = 1
             source, meta = self._emit(trial)
-            hsaco = hb.compile_module(source, self.tmp_dir,
-                                      self.show_compile_output,
-                                      opt_level=opt_level)
+            hsaco = self._compile(source, opt_level=opt_level)
             return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta), trial
 
         from concurrent.futures import ThreadPoolExecutor
@@ -678,9 +699,9 @@ class ConstraintCollocator(object):
             # the least-spilling cut built WITHOUT that stage -- and a loud
             # warning: run ``cross_check()`` on such a problem.
             source, meta = best[3]
-            hsaco = hb.compile_module(
-                source, self.tmp_dir, self.show_compile_output,
-                extra_flags=hb.SAFE_SCHEDULER_FLAGS, opt_level=opt_level)
+            hsaco = self._compile(
+                source, extra_flags=hb.SAFE_SCHEDULER_FLAGS,
+                opt_level=opt_level)
             logger.warning('kernels %s spill vector registers to scratch '
                            'memory whatever the cut (%d states, %d entries '
                            'per block, launches of %d blocks): built with %s; '
@@ -757,9 +778,8 @@ class ConstraintCollocator(object):
             for k, v in okw.items():
                 setattr(opts, k, v)
             source, m = self._emit(opts)
-            hsaco = hb.compile_module(
-                source, self.tmp_dir, self.show_compile_output,
-                opt_level=how.get('opt_level'),
+            hsaco = self._compile(
+                source, opt_level=how.get('opt_level'),
                 extra_flags=tuple(how.get('extra_flags', ())))
             return label, opts, how, source, m, hsaco
 
@@ -1082,9 +1102,7 @@ class ConstraintCollocator(object):
         import torch
         hip = self._ensure_hip()
         meta = self._kernel_meta
-        hsaco = hb.compile_module(self._built_source, self.tmp_dir,
-                                  self.show_compile_output,
-                                  opt_level=opt_level)
+        hsaco = self._compile(self._built_source, opt_level=opt_level)
         twin = hb.HipProblem(self._descriptor(meta), hsaco)
         try:
             self._install_tables(twin)

@@ -156,6 +156,11 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
 SAFE_SCHEDULER_FLAGS = ('-mllvm',
                         '-amdgpu-disable-unclustered-high-rp-reschedule')
 
+#: hipcc switch of ``ConstraintCollocator(deterministic=True)``: every
+#: floating-point operation rounds on its own (no mul + add -> fma), so an
+#: entry's value does not depend on which wave's straight-line code holds it
+DETERMINISTIC_FLAGS = ('-ffp-contract=off',)
+
 _RESOURCE_KEYS = ('.vgpr_count', '.agpr_count', '.sgpr_count',
                   '.vgpr_spill_count', '.sgpr_spill_count',
                   '.private_segment_fixed_size', '.group_segment_fixed_size')

@@ -3,7 +3,10 @@
 (fused, separate, constraints only, Jacobian only; contiguous shard buffers
 and strided in-place destinations) against the whole-problem evaluation of
 the same handle -- the values of a node must not depend on the launch it is
-evaluated in."""
+evaluated in.  OPTY_SOAK_DETERMINISTIC=1: the collocators are built with
+``deterministic=True`` and EVERY window -- fused or separate kernels, any
+offset -- must equal ONE whole-problem evaluation bit for bit (and the fused
+launch the separate ones).  Without a GPU the modules are only prebuilt."""
 import os, sys, random
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, REPO)
@@ -15,7 +18,8 @@ from examples import problems
 
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(3)
-dev = torch.device('cuda:0')
+DET = os.environ.get('OPTY_SOAK_DETERMINISTIC') == '1'
+dev = torch.device('cuda:0') if torch.cuda.is_available() else None
 bad = total = rounding = 0
 for name, nodes in (('config3_10link_small', 5003),
                     ('gaitlike_3link_be_small', 3001),
@@ -26,8 +30,11 @@ for name, nodes in (('config3_10link_small', 5003),
                     ('one_legged_small', 2051),
                     ('elementary_be_small', 3333)):
     factory, fkw = problems.CONFIGS[name]
-    col = opty_amd.ConstraintCollocator(**factory(**dict(fkw,
-                                                         num_nodes=nodes)))
+    col = opty_amd.ConstraintCollocator(deterministic=DET, **factory(
+        **dict(fkw, num_nodes=nodes)))
+    if dev is None:
+        print(name, os.path.basename(col.prebuild()[0]), flush=True)
+        continue
     hip = col.hip
     hip.use_torch_stream()
     free_h = problems.make_free(col.num_free, seed=5,
@@ -51,6 +58,13 @@ for name, nodes in (('config3_10link_small', 5003),
     hip.eval_jac(free, jac, hb.DEVICE)
     torch.cuda.synchronize()
     separate_ref = (con[:M*ncn].view(M, ncn), jac[:P*ncn].view(ncn, P))
+    if DET:
+        # one set of values, whatever kernel produced them
+        if not (torch.equal(fused_ref[0], separate_ref[0]) and
+                torch.equal(fused_ref[1], separate_ref[1])):
+            bad += 1
+            print('MISMATCH', name, 'fused != separate', flush=True)
+        fused_ref = separate_ref
     for k in range(count):
         a = rng.randrange(0, ncn)
         b = min(ncn, a + rng.choice([1, 2, 63, 64, 65, 127, 200,
@@ -104,12 +118,15 @@ for name, nodes in (('config3_10link_small', 5003),
                 worst = max(worst, float(torch.nan_to_num(d).max() /
                                          jac2d[a:b].abs().max()))
             rounding += 1
-            if nans or worst > 1e-13:
+            if nans or worst > 1e-13 or DET:
                 bad += 1
                 print('MISMATCH', name, a, b, what, in_place, 'NaN', nans,
                       'worst', worst, flush=True)
     hip.close()
-print('window soak: %d windows, %d bit-identical, %d equal to rounding '
+if dev is None:
+    sys.exit(0)
+print('window soak%s: %d windows, %d bit-identical, %d equal to rounding '
       '(<= 1e-13 of the largest value, no unwritten value), %d mismatches'
-      % (total, total - rounding, rounding - bad, bad))
+      % (' (deterministic builds)' if DET else '', total, total - rounding,
+         max(0, rounding - bad), bad))
 sys.exit(1 if bad else 0)
