@@ -356,7 +356,7 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
         # takes 140 us + 189 us on one core
         import numpy as np
         hip.set_stream(None)
-        cf = col.generate_constraint_function()
+        cf = col.generate_constraint_function(recycle=True)
         jf = col.generate_jacobian_function()
         hf = [problems.make_free(col.num_free, seed=s) for s in range(3)]
         lat = {}
@@ -404,7 +404,8 @@ def host_path(kw, dev_index, reps=7):
         col = opty_amd.ConstraintCollocator(device=dev_index, **extra, **kw)
         frees = [problems.make_free(col.num_free, seed=s) for s in range(3)]
         if not label:
-            out['con'] = med(col.generate_constraint_function(), frees)
+            out['con'] = med(col.generate_constraint_function(recycle=True),
+                             frees)
             dense = hb.pinned_empty(col.hip.nnz)
             out['jac_dense_copy'] = med(
                 lambda f: col.hip.eval_jac(f, dense, hb.HOST), frees)

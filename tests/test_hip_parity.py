@@ -861,7 +861,14 @@ def test_constraint_arrays_are_fresh_to_the_caller():
     many are kept; a result that was dropped may lend its page-locked memory
     to a later call."""
     col = _collocator('config2_pendulum_small')
-    con = col.generate_constraint_function()
+    # the default: a new array per call, no bookkeeping at all
+    plain = col.generate_constraint_function()
+    f0 = problems.make_free(col.num_free, seed=0)
+    a, b = plain(f0), plain(f0)
+    assert a is not b and a.ctypes.data != b.ctypes.data
+    np.testing.assert_array_equal(a, b)
+    # opt-in recycling of page-locked arrays (what Problem's callbacks use)
+    con = col.generate_constraint_function(recycle=True)
     frees = [problems.make_free(col.num_free, seed=s) for s in range(8)]
     kept = [con(f) for f in frees]              # more than the ring holds
     copies = [k.copy() for k in kept]
@@ -1003,50 +1010,96 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
     assert col6.hip is not None          # the documented opt-out
 
 
+FROZEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..',
+                      'tools', 'o3_repro')
+
+
+def frozen_module(tag):
+    """``(source, info)`` of a module whose hipcc build is WRONG, frozen with
+    the device header inlined under ``tools/o3_repro/`` (``info``: problem,
+    compiler switches, launch metadata, what was observed) -- compiler-fault
+    evidence that does not follow the printer."""
+    import json
+    import lzma
+    with lzma.open(os.path.join(FROZEN, tag + '.hip.xz'), 'rt') as f:
+        source = f.read()
+    with open(os.path.join(FROZEN, tag + '.json')) as f:
+        return source, json.load(f)
+
+
+def frozen_verdict(tag, tmp_dir=None):
+    """Compiles a frozen module as recorded and holds it to the instruction
+    tape of ITS problem: ``(errors per kernel, collocator)``."""
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    source, info = frozen_module(tag)
+    kw = dict(info['collocator_kwargs'])
+    if info.get('launch_nodes'):
+        kw['launch_nodes'] = info['launch_nodes']
+    col = opty_amd.ConstraintCollocator(**kw,
+                                        **problems.build(info['problem']))
+    hsaco = hb.compile_module(source, tmp_dir or col.tmp_dir,
+                              opt_level=info['opt_level'])
+    res = hb.cached_kernel_resources(hsaco)
+    for k, want in info['resources'].items():
+        # the build the record describes (same compiler, same allocation)
+        assert {q: res[k][q] for q in want} == want, (k, res[k], want)
+    try:
+        col._verify_build(hsaco, info['meta'], force=True)
+    except hb.BuildRejected as err:
+        return err.verdict['errors'], col
+    return None, col
+
+
+@pytest.mark.gpu
 def test_row_sorted_muscle_model_o1_twin_is_the_faulty_one():
     """Round 4's first find, kept as a regression test of the CHECK (not of
     the compiler): the ``-O1`` build of the row-sorted module of the
     muscle-driven leg has a Jacobian kernel that is 2.7 % off WITHOUT
-    spilling vector registers.  The build in use passes the referee; the
-    ``-O1`` twin -- if this compiler still miscompiles it -- does not."""
+    spilling vector registers (504 VGPRs, 373 spilled SGPRs).  The module is
+    frozen (``tools/o3_repro/one_legged_csr_O1``: the printer has moved on and
+    its modules no longer trigger the fault), so the referee is shown a REAL
+    wrong build on every box; the collocator's own build of the same problem
+    passes."""
     import opty_amd
-    from opty_amd import hip_backend as hb
-    kw = problems.build('one_legged_small')
-    col = opty_amd.ConstraintCollocator(jacobian_layout='csr', **kw)
+    errors, _ = frozen_verdict('one_legged_csr_O1')
+    assert errors is not None, 'the referee accepted a build known wrong'
+    assert errors['opty_jac'] > 1e-4 and errors['opty_con'] < 1e-11, errors
+    col = opty_amd.ConstraintCollocator(
+        jacobian_layout='csr', **problems.build('one_legged_small'))
     col.hip
-    verdict = col._build_verdict
-    assert verdict['ok'] and verdict['worst'] < 1e-11, verdict
-    twin = hb.compile_module(col._built_source, col.tmp_dir, opt_level='-O1')
-    try:
-        col._verify_build(twin, col._kernel_meta, force=True)
-    except hb.BuildRejected as err:
-        assert err.verdict['errors']['opty_jac'] > 1e-9
-    else:
-        pytest.skip('this hipcc compiles the -O1 twin correctly')
+    assert col._build_verdict['ok'] and col._build_verdict['worst'] < 1e-11
 
 
+@pytest.mark.gpu
 def test_biped_build_with_twenty_strips_is_refused():
     """Round 4's second find: the spill-free ``-O2`` build of the
-    seven-segment biped with the printer's default 20 strips returns the
+    seven-segment biped with 20 even strips (498 / 508 VGPRs) returns the
     SAME wrong strip 17 from its separate and its fused Jacobian kernel
     (220 entries off against the reference golden), and a twin from another
-    pipeline agrees with it -- a consensus of builds accepted it.  The
-    instruction tape does not; the collocator's own (pinned) build matches
-    the reference (``test_golden_full[biped_small]``)."""
-    import opty_amd
-    from opty_amd import hip_backend as hb
-    from opty_amd.codegen.emit_hip import EmitOptions
-    kw = problems.build('biped_small')
-    col = opty_amd.ConstraintCollocator(
-        emit_options=EmitOptions(groups=20, fused_groups=20), **kw)
-    try:
-        col.hip
-    except hb.BuildRejected as err:
-        assert err.verdict['errors']['opty_jac'] > 1e-3
-        assert err.verdict['errors']['opty_conjac'] > 1e-3
-        assert err.verdict['errors']['opty_con'] < 1e-11
-    else:
-        pytest.skip('this hipcc compiles the 20-strip build correctly')
+    pipeline agreed with it -- a consensus of builds accepted it.  The
+    instruction tape does not (frozen module: ``tools/o3_repro/
+    biped_20_strips_O2``); the collocator's own build matches the reference
+    (``test_golden_full[biped_small]``)."""
+    errors, _ = frozen_verdict('biped_20_strips_O2')
+    assert errors is not None, 'the referee accepted a build known wrong'
+    assert errors['opty_jac'] > 1e-3 and errors['opty_conjac'] > 1e-3
+    assert errors['opty_con'] < 1e-11, errors
+
+
+@pytest.mark.gpu
+def test_spilling_parked_wave_is_refused():
+    """Round 5's find: a planned wave with LDS parking whose Jacobian-only
+    kernel spills 72 vector registers at ``-O2`` returns garbage (7.8 x the
+    row scale) while the fused kernel of the same module -- same expressions,
+    no vector spills -- is right (``tools/o3_repro/
+    one_legged_park_spill_O2``).  The class every wrong build of round 3
+    belonged to; the collocator never uses such a build (spill guard), the
+    referee refuses it as well."""
+    errors, _ = frozen_verdict('one_legged_park_spill_O2')
+    assert errors is not None, 'the referee accepted a build known wrong'
+    assert errors['opty_jac'] > 1e-2, errors
+    assert errors['opty_conjac'] < 1e-11 and errors['opty_con'] < 1e-11
 
 
 @pytest.mark.gpu
