@@ -809,10 +809,14 @@ class _WavePlan(object):
 
 class _ModuleWriter(object):
 
-    def __init__(self, prog, opts, inline_uniform=False):
+    def __init__(self, prog, opts, inline_uniform=False, literals=None):
         self.p = prog
         self.o = opts
         self.dag = prog.dag
+        #: node-invariant nodes whose VALUES are printed (node -> float;
+        #: ConstraintCollocator(specialize_parameters=True)) instead of read
+        #: from the table opty_uni fills
+        self.literals = literals or {}
         # True: no uni[] table -- node-invariant INPUTs are scalar loads from
         # their homes and what depends on them is computed in every lane
         self.inline_uni = bool(inline_uniform)
@@ -844,6 +848,8 @@ class _ModuleWriter(object):
         d = self.dag
         if not d.uni[i] or d.op[i] == ir.CONST:
             return False
+        if i in self.literals:
+            return True
         if self.inline_uni or (self.inline_dynamic and self._dynamic(i)):
             return d.op[i] == ir.INPUT
         return True
@@ -1294,6 +1300,8 @@ class _ModuleWriter(object):
                 off = p.cur_offset if kind == 'cur' else p.adj_offset
                 return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
             if self._uniform_leaf(i):
+                if i in self.literals:
+                    return _lit(self.literals[i])
                 if self.inline_uni or (self.inline_dynamic and
                                        self._dynamic(i)):
                     return self._scalar_source(i)
@@ -2166,7 +2174,7 @@ def emit_matrix_module(prog, opts=None):
     return source, meta
 
 
-def emit_module(prog, opts=None, node_blocks=None):
+def emit_module(prog, opts=None, node_blocks=None, literals=None):
     """Returns ``(source, meta)``; ``meta`` describes the launch geometry the
     runtime needs (waves per node block, size of the ``uni`` table, whether
     the table depends on ``free``).  ``node_blocks``: 64-node blocks of the
@@ -2186,7 +2194,7 @@ def emit_module(prog, opts=None, node_blocks=None):
             sum(1 for i in range(len(prog.dag.op)) if prog.dag.uni[i] and
                 prog.dag.op[i] not in (ir.CONST, ir.INPUT)) \
             <= INLINE_UNIFORM_MAX_NODES
-    w = _ModuleWriter(prog, opts, inline)
+    w = _ModuleWriter(prog, opts, inline, literals)
     groups = w.group_ranges()
     # Constraint rows may be split over several waves (contiguous row ranges):
     # one wave evaluating all M defects of a big system runs out of registers.
@@ -2241,7 +2249,7 @@ def emit_module(prog, opts=None, node_blocks=None):
                                            len(dual_sets), int(node_blocks))
             if dual is not None:
                 opts, fused = dual
-                w = _ModuleWriter(prog, opts, inline)
+                w = _ModuleWriter(prog, opts, inline, literals)
                 groups = w.group_ranges(fused)
                 alone_sets = con_sets = dual_sets
             elif node_blocks:
@@ -2355,4 +2363,6 @@ def emit_module(prog, opts=None, node_blocks=None):
                 sha=hashlib.sha256(source.encode()).hexdigest())
     if w._plans:
         meta['plans'] = w._plans
+    if literals:
+        meta['literals'] = len(literals)
     return source, meta

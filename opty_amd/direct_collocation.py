@@ -76,7 +76,22 @@ class ConstraintCollocator(object):
                  show_compile_output=False, backend='hip', device=0,
                  emit_options=None, prune_zeros=False,
                  jacobian_layout='coo', launch_nodes=None,
-                 deterministic=False, verify_builds=None):
+                 deterministic=False, verify_builds=None,
+                 specialize_parameters=False):
+        # opt-in: the node-invariant sub-expressions (products of masses and
+        # lengths, 1/h ...) are printed into the kernels as float64 literals,
+        # computed on the host from the known parameter values and the fixed
+        # node time interval at build time, instead of being read from the
+        # table opty_uni fills: no scalar loads, no scalar registers spilled
+        # into vector lanes in the waves at the register limit (the
+        # muscle-driven leg: -11 %).  The module is then specific to those
+        # values: when known_parameter_map changes between calls (it is
+        # re-read on every call, as in the reference) the kernels are printed
+        # and compiled again -- seconds, not microseconds: for solves with
+        # fixed parameters.
+        self._specialize = bool(specialize_parameters)
+        self._specialized_for = None
+        self._literal_values = None
         # how builds are held to the expression DAG before their first use
         # (:meth:`_verify_build`): None = the environment (OPTY_CROSS_CHECK)
         # or every build; 'all', 'hot' (only kernels at the register limit)
@@ -589,7 +604,49 @@ class ConstraintCollocator(object):
 
     def _emit(self, opts):
         return emit_module(self._build_program(), opts,
-                           node_blocks=self._launch_blocks())
+                           node_blocks=self._launch_blocks(),
+                           literals=self._literals())
+
+    def _known_scalars(self):
+        """``(known parameter values, fixed interval or None)`` as the
+        kernels get them."""
+        par = tuple(float(self.known_parameter_map[p])
+                    for p in self.known_parameters)
+        h = None if self._variable_duration else \
+            float(self.node_time_interval)
+        return par, h
+
+    def _literals(self):
+        """``{node: value}`` of the node-invariant nodes of the program
+        that do not depend on ``free``, for the CURRENT known parameter
+        values (``specialize_parameters=True``), or None."""
+        if not self._specialize:
+            return None
+        from .codegen.evaluate import evaluate_uniform
+        from .codegen import ir
+        prog = self._build_program()
+        par, h = self._known_scalars()
+        if self._specialized_for == (par, h) and \
+                self._literal_values is not None:
+            return self._literal_values
+        d = prog.dag
+
+        def scalar(kind, idx):
+            if kind == 'par':
+                src, k = prog.pars[idx]
+                return par[k] if src == 'known' else None
+            if kind == 'h':
+                return h if prog.h[0] == 'fixed' else None
+            return None
+
+        roots = [i for i in d.reachable(
+            set(prog.con_out) | set(prog.jac_out) |
+            set(prog.inst_con_out or ()) | set(prog.inst_jac_out or ()))
+            if d.uni[i] and d.op[i] != ir.CONST]
+        vals = evaluate_uniform(d, roots, scalar)
+        self._literal_values = {i: vals[i] for i in roots if i in vals}
+        self._specialized_for = (par, h)
+        return self._literal_values
 
     def _build_code_object(self, opt_level=None):
         """Emits and compiles this problem's module; returns ``(hsaco path,
@@ -1286,6 +1343,21 @@ class ConstraintCollocator(object):
         self._hip = hip
         return hip
 
+    def _respecialize(self, hip):
+        self._literal_values = None
+        hsaco, meta = self._build_code_object()
+        try:
+            self._build_verdict = self._verify_build(hsaco, meta)
+        except hb.BuildRejected as err:
+            if self._emit_options is not None or self._pinned is not None:
+                raise
+            hsaco, meta, self._build_verdict = self._verified_alternative(
+                hsaco, meta, err)
+        hip.reload(self._descriptor(meta), hsaco)
+        self._kernel_meta = meta
+        self._uploaded_parameters = self._uploaded_trajectories = None
+        self._install_tables(hip)
+
     def _install_tables(self, hip):
         """Uploads the node-invariant data of this problem into a handle."""
         if not self._variable_duration:
@@ -1336,6 +1408,15 @@ class ConstraintCollocator(object):
         re-uploaded only when they differ.  Known trajectories given as
         functions of ``free`` (``:2916-2917``) are re-evaluated on the host
         every call; ``free`` is None at setup, when those are skipped."""
+        if self._specialize and hip is self._hip and \
+                self._specialized_for is not None and \
+                self._known_scalars() != self._specialized_for:
+            # the kernels carry the OLD values as literals: print, compile
+            # and verify them again for the new ones, inside the same handle
+            # object (closures hold on to it)
+            logger.warning('known parameters changed: rebuilding the '
+                           'parameter-specialised kernels')
+            self._respecialize(hip)
         if self.num_known_parameters:
             vals = np.array([float(self.known_parameter_map[p])
                              for p in self.known_parameters])

@@ -546,9 +546,24 @@ class HipProblem(object):
 
     __del__ = close
 
+    def reload(self, desc, hsaco_path):
+        """Replaces the C handle behind this object by one for another code
+        object of the same problem (kernels specialised for new parameter
+        values); tables and stream have to be installed again."""
+        new = _P()
+        d = _Desc(**desc)
+        _check(self._lib.opty_hip_create(ctypes.byref(d), hsaco_path.encode(),
+                                         ctypes.byref(new)))
+        self.close()
+        self._h = new
+        self.desc = dict(desc)
+        if getattr(self, '_stream_ptr', None):
+            self.set_stream(self._stream_ptr)
+
     # -- configuration -------------------------------------------------------
     def set_stream(self, stream_ptr):
         _check(self._lib.opty_hip_set_stream(self._h, stream_ptr))
+        self._stream_ptr = stream_ptr
 
     def use_torch_stream(self, stream=None):
         """Run this handle's work on a torch stream (default: the current

@@ -306,14 +306,16 @@ def candidates(prog, node_blocks):
         # blocks bound by their arithmetic (unequal waves, one per SIMD): the
         # dispatch order of a launch's workgroups, and cuts with fewer long
         # strips whose waves park values in LDS
-        for order in ('class', 'tail'):
-            out.append(('jac:%s' % order, dict(seed, order=order)))
-            out.append(('fused:%s' % order, dict(seed, fused_order=order)))
         shapes = [('', {})]
         if g['chunk'] == 32 and not g['occupancy']:
             shapes.append(('c16:', dict(chunk=16)))     # 17 KB less ring
         for pre, shape in shapes:
             base = dict(seed, **shape)
+            for order in ('class', 'tail'):
+                out.append(('jac:%s%s' % (pre, order),
+                            dict(base, order=order)))
+                out.append(('fused:%s%s' % (pre, order),
+                            dict(base, fused_order=order)))
             for tag, spec in _merged_cuts(prog, base, g):
                 for live in (235, 225):
                     kw = dict(base, fused_strips=spec, park=48,
@@ -431,7 +433,8 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
             # one that changes the shape of ALL kernels of the module (chunk
             # width / workgroup width) by more than box-to-box spread
             margin = 0.0 if label == 'seed' else (
-                0.01 if '=' in label else 0.03)
+                0.01 if ('=' in label or label.startswith(('jac', 'fused')))
+                else 0.03)
             # ... and by more than the resolution of a microsecond-scale
             # launch
             if what not in best or (ms < best[what][0]*(1.0 - margin) and

@@ -32,6 +32,18 @@ def test_deterministic_builds_are_their_own_modules():
     assert not hb.vgpr_spills(h_det)
 
 
+def prebuild():
+    """Code objects of the GPU test below (``__graft_entry__.build``)."""
+    from opty_amd.sharded import partition_nodes
+    nodes = 2051
+    for name in NAMES:
+        _scaled(name, nodes).prebuild()
+        for world in (2, 3, 8):
+            ranges = partition_nodes(nodes - 1, world)
+            _scaled(name, nodes,
+                    launch_nodes=max(b - a for a, b in ranges)).prebuild()
+
+
 def _scaled(name, nodes, **extra):
     factory, fkw = problems.CONFIGS[name]
     return opty_amd.ConstraintCollocator(
@@ -75,9 +87,11 @@ def test_any_launch_returns_the_same_bits(name):
     c2, j2 = torch.empty_like(con), torch.empty_like(jac)
     std.hip.eval_con_jac(free, c2, j2, hb.DEVICE)
     torch.cuda.synchronize()
+    # (1e-10 of the largest value: the muscle model's 1/h^2-sized entries
+    # round at 1e-5 absolute, and contraction moves an entry by a few such)
     for got, want in ((con, c2), (jac, j2)):
         scale = float(want.abs().max())
-        assert float((got - want).abs().max()) <= 1e-11*scale
+        assert float((got - want).abs().max()) <= 1e-10*scale
     std.hip.close()
     # node windows at every alignment, through every selector
     rng = np.random.default_rng(5)

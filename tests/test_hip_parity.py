@@ -306,6 +306,78 @@ def test_known_maps_are_re_read_on_every_call():
     check('trajectory replaced')
 
 
+SPECIALISED = ['config3_10link_small', 'one_legged_small', 'biped_small',
+               'msd_be_small', 'pend2_link_vardur_unkmass_small']
+
+
+@pytest.mark.parametrize('name', SPECIALISED)
+def test_parameter_specialised_kernels_match_the_reference(name):
+    """``specialize_parameters=True``: node-invariant sub-expressions as
+    float64 literals computed on the host at build time (no table, no scalar
+    loads) -- same golden, same tolerance as the default build."""
+    import opty_amd
+    meta, z = gu.load(name)
+    factory, fkw = problems.CONFIGS[name]
+    col = opty_amd.ConstraintCollocator(specialize_parameters=True,
+                                        **factory(**fkw))
+    con = col.generate_constraint_function()(z['free'])
+    jac = col.generate_jacobian_function()(z['free'])
+    assert col._kernel_meta.get('literals', 0) > 0 or \
+        col.num_known_parameters == 0
+    cb, jb = gu.error_bounds(col, z['free'])
+    N1, M, C = meta['N'] - 1, meta['M'], meta['C']
+    ccap, jcap = gu.row_caps(z['jac'][:N1*M*C].reshape(N1, M, C))
+    ccap = np.concatenate((ccap.ravel(),
+                           np.full(len(z['con']) - N1*M, np.inf)))
+    jcap = np.concatenate((jcap.ravel(),
+                           np.full(len(z['jac']) - N1*M*C, np.inf)))
+    gu.assert_close(con, z['con'], RTOL, what=name + ' specialised con',
+                    bound=cb, cap=ccap)
+    gu.assert_close(jac, z['jac'], RTOL, what=name + ' specialised jac',
+                    bound=jb, cap=jcap)
+    # the fused launch of the same handle
+    import torch
+    from opty_amd import hip_backend as hb
+    c2 = np.empty_like(con)
+    j2 = np.empty_like(jac)
+    col.hip.eval_con_jac(z['free'], c2, j2, hb.HOST)
+    gu.assert_close(c2, z['con'], RTOL, what=name + ' specialised fused con',
+                    bound=cb, cap=ccap)
+    gu.assert_close(j2, z['jac'], RTOL, what=name + ' specialised fused jac',
+                    bound=jb, cap=jcap)
+
+
+def test_specialised_kernels_follow_the_parameter_map():
+    """The literals are the parameter values of the build: when
+    ``known_parameter_map`` changes between calls (the reference re-reads it
+    on every call, ``opty/direct_collocation.py:2891-2926``) the kernels are
+    printed and compiled again inside the same handle; closures made before
+    the change keep working."""
+    from oracle.collocation_oracle import OracleCollocator
+    import opty_amd
+    kw = problems.mass_spring_damper(num_nodes=150)
+    col = opty_amd.ConstraintCollocator(specialize_parameters=True, **kw)
+    con = col.generate_constraint_function()
+    jac = col.generate_jacobian_function()
+    free = problems.make_free(col.num_free, seed=2)
+
+    def check(tag):
+        orc = OracleCollocator(name='msd_mutated', **kw)
+        gu.assert_close(con(free), orc.generate_constraint_function()(free),
+                        RTOL, what='con ' + tag)
+        gu.assert_close(jac(free), orc.generate_jacobian_function()(free),
+                        RTOL, what='jac ' + tag)
+
+    check('initial')
+    first = col._kernel_meta['sha']
+    m = list(kw['known_parameter_map'])[0]
+    col.known_parameter_map[m] = 1.625
+    check('parameter changed')
+    assert col._kernel_meta['sha'] != first      # other literals: other module
+    col.known_parameter_map[m] = 0.75
+    check('parameter changed again')
+
+
 def test_stream_switch_orders_the_invariant_table():
     """A handle whose node-invariant table depends on ``free`` (unknown
     parameters, variable h), used alternately on two streams: every launch
@@ -1025,6 +1097,28 @@ def frozen_module(tag):
         source = f.read()
     with open(os.path.join(FROZEN, tag + '.json')) as f:
         return source, json.load(f)
+
+
+def prebuild_extras():
+    """Code objects of the frozen compiler-fault modules and of the
+    parameter-specialised builds (``__graft_entry__.build``)."""
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    for tag in ('one_legged_csr_O1', 'biped_20_strips_O2',
+                'one_legged_park_spill_O2'):
+        source, info = frozen_module(tag)
+        hb.compile_module(source, opt_level=info['opt_level'])
+    for name in SPECIALISED:
+        factory, fkw = problems.CONFIGS[name]
+        opty_amd.ConstraintCollocator(specialize_parameters=True,
+                                      **factory(**fkw)).prebuild()
+    kw = problems.mass_spring_damper(num_nodes=150)
+    m = list(kw['known_parameter_map'])[0]
+    for value in (None, 1.625, 0.75):
+        if value is not None:
+            kw['known_parameter_map'][m] = value
+        opty_amd.ConstraintCollocator(specialize_parameters=True,
+                                      **kw).prebuild()
 
 
 def frozen_verdict(tag, tmp_dir=None):
