@@ -122,6 +122,12 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     ).hexdigest()[:24]
     base = os.path.join(cache_dir, 'opty_' + digest)
     hsaco = base + '.hsaco'
+    manifest = os.environ.get('OPTY_CACHE_MANIFEST')
+    if manifest:
+        # which code objects a run asks for (tools/prune_cache.py keeps
+        # those and drops the leftovers of experiments)
+        with open(manifest, 'a') as f:
+            f.write(os.path.basename(hsaco) + '\n')
     if os.path.exists(hsaco):
         logger.info('code object cache hit: %s', hsaco)
         return hsaco

@@ -296,6 +296,10 @@ def candidates(prog, node_blocks):
     for j in sorted(set(jac_counts)):
         if j != g['jac']:
             out.append(('jac=%d' % j, dict(seed, groups=j)))
+    # one empty wave more per block: r02 measured the Jacobian kernel of the
+    # 10-link system faster with it (dispatch order, not arithmetic)
+    for j in sorted({g['jac'], g['fused']}):
+        out.append(('jac:pad%d' % j, dict(seed, groups=j, pad=1)))
     if g['chunk'] == 32 and not g['occupancy']:
         # shorter ring tiles (16-entry chunks) leave LDS for wider workgroups
         # that share one input slab: fewer slab fills per block, which large
@@ -456,7 +460,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
             # what only the Jacobian kernel reads: its strip count and the
             # dispatch order of its workgroups
             jac_ms, jac_kw = min(same, key=lambda t: t[0])
-            for tag in ('groups', 'order'):
+            for tag in ('groups', 'order', 'pad'):
                 options.pop(tag, None)
                 if tag in jac_kw:
                     options[tag] = jac_kw[tag]

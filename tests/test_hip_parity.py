@@ -956,6 +956,7 @@ def test_constraint_arrays_are_fresh_to_the_caller():
     assert len({id(k) for k in kept}) == len(kept)
     for k, f in zip(kept, frees):
         np.testing.assert_array_equal(k, con(f))
+    del kept, views, k, v                       # nobody looks any more
     a = con(frees[0])
     addr = a.ctypes.data
     del a

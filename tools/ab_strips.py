@@ -39,9 +39,15 @@ def main():
     iters = int(os.environ.get('OPTY_AB_ITERS', 100))
     cols = []
     for spec in args:
-        opts = None if spec == 'auto' else (
-            EmitOptions() if spec == 'default' else parse(spec))
-        col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
+        # "auto+specialize" / "<options>,specialize=1": parameter-specialised
+        # kernels (ConstraintCollocator(specialize_parameters=True))
+        special = 'specialize' in spec
+        bare = spec.replace('+specialize', '').replace(',specialize=1', '') \
+            .replace('specialize=1', '')
+        opts = None if bare in ('auto', '') else (
+            EmitOptions() if bare == 'default' else parse(bare))
+        col = opty_amd.ConstraintCollocator(
+            emit_options=opts, specialize_parameters=special, **kw)
         if not torch.cuda.is_available():
             hsaco, meta = col._build_code_object()      # prebuild only
             print(spec, hb.vgpr_spills(hsaco), flush=True)

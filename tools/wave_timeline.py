@@ -36,7 +36,15 @@ def main():
     kw = factory(**fkw)
     dev = torch.device('cuda:0') if torch.cuda.is_available() else None
     for spec in sys.argv[3:]:
-        opts = parse(spec + ',trace=1')
+        if spec == 'auto':
+            # the geometry a collocator picks by itself (launch plan or the
+            # printer's rules), traced
+            import copy
+            probe = opty_amd.ConstraintCollocator(**kw)
+            opts = copy.copy(probe._printer_options())
+            opts.trace = 1
+        else:
+            opts = parse(spec + ',trace=1')
         col = opty_amd.ConstraintCollocator(emit_options=opts, **kw)
         if dev is None:
             hsaco, meta = col._build_code_object()
