@@ -151,7 +151,14 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
         raise ImportError('Unable to build the HIP code object {}, '
                           'compilation failed. STDERR output from '
                           'compilation:\n{}'.format(src_tmp, proc.stderr))
-    os.replace(src_tmp, base + '.hip')
+    # the printed source is kept next to the code object only on request
+    # (OPTY_KEEP_SOURCES=1: disassembly sessions); 0.8 GB of them travelled
+    # with every GPU lease in r04.  A failed compile leaves its source behind
+    # (the ImportError above names it).
+    if os.environ.get('OPTY_KEEP_SOURCES') == '1':
+        os.replace(src_tmp, base + '.hip')
+    else:
+        os.remove(src_tmp)
     os.replace(hsaco + tag, hsaco)
     return hsaco
 
