@@ -209,6 +209,11 @@ def lookup_traffic(kernel_sha):
         return None
 
 
+#: entries of ``other_configs`` that are also timed with parameter-specialised
+#: kernels (blocks bound by their arithmetic)
+SPECIALISED_ENTRIES = ('config5_one_legged', 'config5_biped')
+
+
 def other_configs(dev, iters):
     """Kernel times and HBM fractions of BASELINE config 2 and of the
     config-5 stand-in on this GPU (hipEvent-timed, single GPU)."""
@@ -325,6 +330,25 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
         # rotates four -- 1-2 % of the bytes of a write stream)
         free_vectors=1,
         build_check=_build_check(col))
+    if name in SPECIALISED_ENTRIES:
+        # opt-in: node-invariant values as literals of the kernels
+        # (ConstraintCollocator(specialize_parameters=True): for solves with
+        # fixed known parameters; rebuilt when they change)
+        spec = opty_amd.ConstraintCollocator(
+            device=dev.index, specialize_parameters=True, **pkw)
+        spec._program = col._program
+        sp = spec.hip
+        sp.use_torch_stream()
+        sres = {}
+        for what, label in whats[:3]:
+            sp.time_eval(what, free, con, jac, max(3, iters//4))
+            sres[label] = sp.time_eval(what, free, con, jac, iters)
+        out[name]['specialised_parameters'] = dict(
+            kernel_ms=sres,
+            fused_hbm_frac=nbytes/(sres['opty_conjac']*1e-3)/1e9 /
+            HBM_PEAK_GBS,
+            build_check=_build_check(spec))
+        sp.close()
     if name.startswith('config5'):
         # one of eight node shards of the same problem (what each GPU of
         # an 8-GPU node launches): its own launch geometry, the global
@@ -835,6 +859,35 @@ def main():
                     'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
                     'what': 'eval + point-to-point gather-v of con and jac to '
                             'rank 0 (%s)' % dist.get_backend()}
+                if not oversub:
+                    # the same gather through the C ABI's own RCCL
+                    # communicator (opty_hip_comm_create / opty_hip_gather_v:
+                    # grouped ncclSend / ncclRecv issued by libopty_hip.so on
+                    # the handle's stream, no PyTorch process group on the data
+                    # path); RCCL refuses duplicate devices, so not when the
+                    # ranks share one GPU
+                    try:
+                        sh.comm = hb.HipComm.from_process_group(
+                            None, device=local_rank)
+                        el = timed(gather_step, args.steps, args.warmup)
+                        if verifier is not None:
+                            sh.evaluate(frees[0], in_place=(rank == 0))
+                            got = sh.gather(0)
+                            if rank == 0:
+                                gc = got[0][:M*ncn].view(M, ncn)
+                                gj = got[1][:P*ncn].view(ncn, P)
+                                verifier.nodes(gc, gj, 0, ncn, 'gather_c_abi')
+                                check_sums(gc, gj, 'gather_c_abi',
+                                           reduce=False)
+                        variants['gather_c_abi'] = {
+                            'evals_per_s': args.steps/el,
+                            'ms_per_step': 1e3*el/args.steps,
+                            'what': 'eval + opty_hip_gather_v to rank 0 (the '
+                                    'library\'s own RCCL communicator)'}
+                    except Exception as err:    # noqa: first contact with RCCL
+                        variants['gather_c_abi'] = {'error': repr(err)[:400]}
+                    finally:
+                        sh.comm = None
                 # a /dev/shm too small for the 810 MB is the one failure that
                 # must not take the headline line down: probe it on rank 0 first
                 # and let every rank know
