@@ -443,8 +443,17 @@ def host_path(kw, dev_index, reps=7):
         # (the default layout's host scatter verifies its thread placement
         # over its first calls -- opty_hip.cpp ScatterPool::feedback; they are
         # warm-up)
-        out['jac' + label] = med(col.generate_jacobian_function(), frees,
-                                 warm=8 if not label else 2)
+        jf = col.generate_jacobian_function()
+        out['jac' + label] = med(jf, frees, warm=14 if not label else 2)
+        if not label:
+            # where the bytes and the threads are (so that a slow line can be
+            # read): NUMA node of the persistent vector, of the scatter
+            # workers, of the device
+            w, d, verified = hb.host_placement()
+            out['placement'] = {
+                'vector_node': hb.host_numa_node(jf(frees[0])),
+                'workers_node': w, 'device_node': d,
+                'verified_by_measurement': verified}
         out['nnz' + label] = col.hip.nnz
         col.hip.close()
     # regression guard: the reference-ordered default layout

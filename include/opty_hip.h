@@ -242,6 +242,12 @@ int opty_hip_set_segments(opty_hip_problem *p, const int32_t *order,
  * ones are moved (beyond it whole blocks are copied and no entry copies are
  * applied): 0.8, or OPTY_HIP_PACK_RATIO. */
 double opty_hip_pack_ratio(void);
+/* Where the host threads that scatter the varying entries run (NUMA node, -1:
+ * unplaced), the NUMA node of the current device, and whether the placement
+ * has been verified by measurement (the pool times its candidates when a
+ * scatter ends late; OPTY_HIP_HOST_PLACEMENT=fixed disables that). */
+int opty_hip_host_placement(int32_t *workers_node, int32_t *device_node,
+                            int32_t *verified);
 /* The same for one node shard of a problem evaluated by several GPUs: the
  * blocks of the constraint nodes [node_begin, node_end), as
  * opty_hip_eval_shard left them in device memory (d_jac_shard), go into the

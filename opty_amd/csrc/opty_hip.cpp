@@ -352,7 +352,7 @@ public:
             cand_.clear();
             exploring_ = -1;
             settled_ = false;
-            bad_streak_ = 0;
+            bad_streak_ = calls_ = sample_ = searches_ = 0;
             want_threads_ = std::max(want_threads_, threads());
         }
         if (exploring_ < 0 && !settled_) set_numa_node(policy_node);
@@ -365,13 +365,33 @@ public:
             const char *e = getenv("OPTY_HIP_HOST_PLACEMENT");
             return e && strcmp(e, "fixed") == 0;
         }();
-        if (settled_ || off) return;
+        if (off) return;
+        ++calls_;
+        // the first calls with a vector fault its pages in and fill the
+        // staging buffers: not measurements
+        if (calls_ <= 3) return;
         const bool bad = lag_ms > std::max(0.6, 0.15*dma_ms);
         if (exploring_ < 0) {
-            if (!bad) { bad_streak_ = 0; return; }
-            if (++bad_streak_ < 2) return;
+            if (settled_) {
+                // keep watching: a placement that was right may stop being
+                // so (another process took those cores); at most two more
+                // searches per vector
+                if (lag_ms <= std::max(0.6, 2.0*best_lag_)) {
+                    bad_streak_ = 0;
+                    return;
+                }
+                if (++bad_streak_ < 5 || searches_ >= 3) return;
+                settled_ = false;
+            } else {
+                if (!bad) { bad_streak_ = 0; return; }
+                if (++bad_streak_ < 2) return;
+            }
+            // every placement is measured afresh, the current one included:
+            // each NUMA node that has CPUs of ours, and the unplaced pool
+            ++searches_;
+            bad_streak_ = 0;
             cand_.clear();
-            cand_.push_back({node_, lag_ms});
+            cand_.push_back({node_, -1.0});
             for (int node = 0; node < 64; ++node) {
                 char path[96];
                 snprintf(path, sizeof path,
@@ -380,11 +400,17 @@ public:
                     cand_.push_back({node, -1.0});
             }
             if (node_ >= 0) cand_.push_back({-1, -1.0});   // unplaced
-            exploring_ = 1;
-        } else {
-            cand_[(size_t)exploring_].second = lag_ms;
-            ++exploring_;
+            exploring_ = 0;
+            sample_ = 0;
+            return;         // the next call measures candidate 0 as it is
         }
+        // two calls per candidate, the better one counts (one late chunk or a
+        // descheduled worker must not decide)
+        auto &cur = cand_[(size_t)exploring_];
+        cur.second = cur.second < 0 ? lag_ms : std::min(cur.second, lag_ms);
+        if (++sample_ < 2) return;
+        sample_ = 0;
+        ++exploring_;
         while (exploring_ < (int)cand_.size()) {
             if (place(cand_[(size_t)exploring_].first)) return;
             cand_[(size_t)exploring_].second = 1e9;     // no CPUs of ours there
@@ -395,6 +421,7 @@ public:
             if (cand_[k].second >= 0 && cand_[k].second < cand_[best].second)
                 best = k;
         place(cand_[best].first);
+        best_lag_ = cand_[best].second;
         settled_ = true;
         exploring_ = -1;
         if (trace) {
@@ -405,6 +432,8 @@ public:
             fprintf(stderr, "\n");
         }
     }
+
+    bool settled() const { return settled_; }
 
     void request_threads(int n) {
         std::lock_guard<std::recursive_mutex> lk(busy_);
@@ -602,6 +631,8 @@ private:
     const void *vector_ = nullptr;   // the vector the placement was chosen for
     std::vector<std::pair<int, double>> cand_;  // (node, lag) while exploring
     int exploring_ = -1, bad_streak_ = 0, want_threads_ = 0;
+    int calls_ = 0, sample_ = 0, searches_ = 0;
+    double best_lag_ = 0.0;
     bool settled_ = false;
     std::vector<std::thread> workers_;
     std::mutex m_;
@@ -867,11 +898,51 @@ int ensure(T **ptr, size_t count) {
 // is used
 #define OPTY_LATENCY_PATH_BYTES (2u << 20)
 
+// NUMA node of the current HIP device (its PCI function's numa_node in
+// sysfs; -1: unknown / one node).
+int device_numa_node() {
+    int dev = 0;
+    char bdf[64] = {0}, path[160];
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetPCIBusId(bdf, sizeof bdf, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    return node;
+}
+
+// Page-locked host memory next to the current device.  It lands where the
+// calling thread's memory policy puts it; a vector on the other socket than
+// the GPU costs the DMA its rate (one box of r05: 4.6 ms per Jacobian next to
+// the GPU, 7.7 ms across the socket link).  So the GPU's node is PREFERRED for
+// the duration of the allocation (MPOL_PREFERRED; a container that refuses
+// set_mempolicy keeps its default; OPTY_HIP_HOST_ALLOC_ANYWHERE=1 opts out).
+hipError_t pinned_alloc(void **ptr, size_t bytes) {
+    const int node = device_numa_node();
+    bool bound = false;
+    if (node >= 0 && node < 64 && !getenv("OPTY_HIP_HOST_ALLOC_ANYWHERE")) {
+        unsigned long mask = 1UL << node;
+        bound = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, &mask,
+                        65UL) == 0;
+    }
+    hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+    if (bound)
+        (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0UL);
+    return e;
+}
+
 template <typename T>
 int ensure_pinned(T **ptr, size_t count) {
     if (*ptr == nullptr && count > 0)
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(ptr), count*sizeof(T),
-                              hipHostMallocDefault));
+        HIP_TRY(pinned_alloc(reinterpret_cast<void **>(ptr),
+                             count*sizeof(T)));
     return 0;
 }
 
@@ -1398,7 +1469,7 @@ int opty_hip_matrix_eval(opty_hip_matrix *m, double *result,
 void *opty_hip_host_alloc(size_t bytes) {
     void *ptr = nullptr;
     if (bytes == 0) bytes = 8;
-    hipError_t e = hipHostMalloc(&ptr, bytes, hipHostMallocDefault);
+    hipError_t e = pinned_alloc(&ptr, bytes);
     if (e != hipSuccess) {
         fail("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return nullptr;
@@ -1856,6 +1927,15 @@ int opty_hip_set_host_threads(int32_t count) {
 
 int opty_hip_host_threads(void) { return ScatterPool::instance().threads(); }
 
+int opty_hip_host_placement(int32_t *workers_node, int32_t *device_node,
+                            int32_t *verified) {
+    ScatterPool &pool = ScatterPool::instance();
+    if (workers_node) *workers_node = pool.numa_node();
+    if (device_node) *device_node = device_numa_node();
+    if (verified) *verified = pool.settled() ? 1 : 0;
+    return 0;
+}
+
 int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
                                  int32_t count) {
     if (!p) return fail("null handle");
@@ -2006,8 +2086,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         p->d_packed = p->h_packed = nullptr;
         p->packed_cap = 0;
         HIP_TRY(hipMalloc((void **)&p->d_packed, packed*sizeof(double)));
-        HIP_TRY(hipHostMalloc((void **)&p->h_packed, packed*sizeof(double),
-                              hipHostMallocDefault));
+        HIP_TRY(pinned_alloc((void **)&p->h_packed, packed*sizeof(double)));
         p->packed_cap = packed;
     }
     // chunks of about 16 MB: long enough for the DMA engine's full rate,

@@ -352,6 +352,7 @@ _SIGNATURES = {
     'opty_hip_set_host_threads': (ctypes.c_int, [ctypes.c_int32]),
     'opty_hip_host_threads': (ctypes.c_int, []),
     'opty_hip_host_numa_node': (ctypes.c_int, [_P]),
+    'opty_hip_host_placement': (ctypes.c_int, [_P, _P, _P]),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
@@ -521,6 +522,15 @@ def pack_ratio():
 def host_numa_node(array):
     """NUMA node that holds the first page of a NumPy array (-1: unknown)."""
     return load_library().opty_hip_host_numa_node(array.ctypes.data)
+
+
+def host_placement():
+    """``(scatter workers' NUMA node, the device's NUMA node, verified by
+    measurement)`` -- ``opty_hip_host_placement``."""
+    w, d, v = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _check(load_library().opty_hip_host_placement(
+        ctypes.addressof(w), ctypes.addressof(d), ctypes.addressof(v)))
+    return w.value, d.value, bool(v.value)
 
 
 def host_register(array):

@@ -244,7 +244,8 @@ def test_tune_launch_records_a_plan_and_keeps_the_results(tmp_path,
     plans = json.loads(path.read_text())
     key = lp.key_of(col._build_program(), (20000 + 63)//64)
     assert plans[key]['options'] == entry['options']
-    assert set(entry['measured_ms']) == {'fused', 'jac'}
+    assert set(entry['measured_ms']) == {'fused', 'jac', 'con'}
+    assert isinstance(entry['fused_pays'], bool)
     assert all(v > 0 for v in entry['measured_ms']['fused'].values())
     assert str(entry['seed']['fused']) in entry['measured_ms']['fused']
     opts = lp.lookup(col._build_program(), (20000 + 63)//64)
