@@ -107,6 +107,12 @@ typedef struct opty_hip_desc {
                              The reference evaluates the two callbacks
                              separately in any case
                              (opty/direct_collocation.py:498-562)            */
+    int32_t jac_via_fused; /* 1: the launch plan measured opty_conjac FASTER than
+                             opty_jac for this problem and launch size (the
+                             constraint waves ride in the shadow of the store
+                             stream): OPTY_HIP_EVAL_JAC launches the fused
+                             kernel, its constraint values go to a scratch
+                             vector of the handle                            */
 } opty_hip_desc;
 
 /* Version of this header's structs and signatures; opty_hip_abi_version()

@@ -664,6 +664,7 @@ struct opty_hip_problem {
     int *d_pattern = nullptr;   // (j, k) per stored block entry when pruned
     int *d_rowinfo = nullptr;   // (S_j, L_j) per stored block entry (CSR)
     double *d_free = nullptr, *d_con = nullptr, *d_jac = nullptr;  // staging
+    double *d_con_scratch = nullptr;    // jac_via_fused: discarded values
     long long *d_rows = nullptr, *d_cols = nullptr;                // staging
     double h = 0.0;
     bool have_params = false, have_known = false, have_inst = false,
@@ -816,6 +817,9 @@ int launch_instance(opty_hip_problem *p, const double *free_, double *con_tail,
 // what: OPTY_HIP_EVAL_*; device pointers only.  `with_inst`: the launch
 // covers the whole problem and the instance tails follow the last node's
 // values (node shards leave them to opty_hip_eval_instance).
+template <typename T>
+int ensure(T **ptr, size_t count);
+
 int eval_device(opty_hip_problem *p, int what, const double *free_,
                 double *con, double *jac, const NodeRange &rg,
                 bool with_inst) {
@@ -838,6 +842,23 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
     if (what == OPTY_HIP_EVAL_FUSED && p->d.fused_loses)
         what = OPTY_HIP_EVAL_PAIR;
     if (what == OPTY_HIP_EVAL_FUSED_KERNEL) what = OPTY_HIP_EVAL_FUSED;
+    // ... or the fused kernel faster than the Jacobian-only one
+    // (opty_hip_desc.jac_via_fused): its constraint values go to scratch
+    if (what == OPTY_HIP_EVAL_JAC && p->d.jac_via_fused &&
+        !p->d.fused_loses) {
+        if (int rc = ensure(&p->d_con_scratch, (size_t)p->num_con()))
+            return rc;
+        NodeRange sr{rg.begin, rg.end, p->ncon_nodes()};
+        if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
+                            64*p->d.fused_waves_per_wg, free_,
+                            p->d_con_scratch + rg.begin, jac, sr, folded))
+            return rc;
+        if (tails && !folded)
+            if (int rc = launch_instance(
+                    p, free_, nullptr, jac + (rg.end - rg.begin)*p->P()))
+                return rc;
+        return 0;
+    }
     if (what == OPTY_HIP_EVAL_CON || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_con, p->d.con_wgs_per_block,
                             64*p->d.con_waves_per_wg, free_, con, nullptr, rg,
@@ -1578,7 +1599,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
                     p->d_known, p->d_inst_idx, p->d_inst_rows,
                     p->d_inst_cols, p->d_free, p->d_con, p->d_jac, p->d_rows,
                     p->d_cols, p->d_var, p->d_packed, p->d_seg_order,
-                    p->d_dense, p->d_seg};
+                    p->d_dense, p->d_seg, p->d_con_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     void *pinned[] = {p->h_packed, p->h_free, p->h_con, p->h_jac};

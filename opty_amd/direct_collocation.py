@@ -729,6 +729,38 @@ class ConstraintCollocator(object):
             return hsaco, meta, hb.vgpr_spills(hsaco), (source, meta), trial
 
         from concurrent.futures import ThreadPoolExecutor
+        if opts.park and best[2]:
+            # a planned wave (LDS parking) that spills: other register
+            # budgets of the plan first -- where spills appear is erratic --,
+            # then the same options without the merged strips / parking
+            def replanned(live):
+                trial = copy.copy(opts)
+                if live is None:
+                    trial.park, trial.fused_strips = 0, None
+                else:
+                    trial.park_live = live
+                if self._deterministic:
+                    trial.deterministic = 1
+                source, meta = self._emit(trial)
+                hsaco = self._compile(source, opt_level=opt_level)
+                return (hsaco, meta, hb.vgpr_spills(hsaco), (source, meta),
+                        trial)
+            lives = [opts.park_live + d for d in (10, -10, -20, -30)
+                     if opts.park_live + d > 100] + [None]
+            logger.info('kernels %s of a plan with LDS parking spill vector '
+                        'registers: other register budgets %s', sorted(
+                            best[2]), lives)
+            with ThreadPoolExecutor(len(lives)) as pool:
+                results = list(pool.map(replanned, lives))
+            clean = [r for r in results if not r[2]]
+            # (a plan that needs more than a quarter of a CU's LDS per wave
+            # costs resident waves: the unmerged fallback comes before it)
+            clean.sort(key=lambda r: max(
+                k['lds_bytes'] for k in r[1]['kernels'].values()) > 40*1024)
+            if clean:
+                best = clean[0]
+                opts, meta = best[4], best[1]
+                geo = meta['geometry']
         phases = [(False, False, list(steps))]
         detachable = bool(meta.get('con_attached')) and \
             opts.con_attach is None
@@ -1302,7 +1334,8 @@ class ConstraintCollocator(object):
             layout={'coo': 0, 'csr': 1,
                     'varying_first': 2}[self._jacobian_layout],
             inst_folded=int(meta.get('inst_folded', False)),
-            fused_loses=self._fused_loses())
+            fused_loses=self._fused_loses(),
+            jac_via_fused=self._plan_flag('jac_via_fused'))
 
     def _fused_loses(self):
         """1 when the launch plan of this problem and launch size measured
@@ -1315,6 +1348,18 @@ class ConstraintCollocator(object):
         entry = launch_plan.lookup_entry(self._build_program(),
                                          self._launch_blocks())
         return int(bool(entry) and entry.get('fused_pays') is False)
+
+    def _plan_flag(self, tag):
+        """1 when the launch plan of this problem and launch size says
+        ``tag`` (``"jac_via_fused": true``: ``EVAL_JAC`` launches the fused
+        kernel, measured faster than ``opty_jac``)."""
+        if self._emit_options is not None or \
+                self._jacobian_layout != 'coo':
+            return 0
+        from . import launch_plan
+        entry = launch_plan.lookup_entry(self._build_program(),
+                                         self._launch_blocks())
+        return int(bool(entry) and entry.get(tag) is True)
 
     def _known_trajectory_array(self, free):
         vals = []

@@ -289,7 +289,8 @@ class _Desc(ctypes.Structure):
             'num_inst', 'nnz_inst', 'num_inst_atoms', 'jac_wgs_per_block',
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device', 'fused_waves_per_wg',
-            'con_waves_per_wg', 'layout', 'inst_folded', 'fused_loses')]
+            'con_waves_per_wg', 'layout', 'inst_folded', 'fused_loses',
+            'jac_via_fused')]
 
 
 class _MatDesc(ctypes.Structure):

@@ -477,7 +477,15 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
     # opty_jac when it does not -- by more than the resolution of the timer)
     fused_pays = best['fused'][0] <= \
         (best['jac'][0] + measured['con'])*1.01 + 3e-4
+    # ... and is the fused kernel even faster than the Jacobian-only one
+    # (10-link pendulum: 0.136 vs 0.139 ms -- the constraint wave rides in
+    # the shadow of the store stream and the 10 waves per block dispatch
+    # better than 12 strips)?  Then EVAL_JAC launches it
+    # (opty_hip_desc.jac_via_fused), by more than run-to-run noise
+    jac_via_fused = fused_pays and \
+        best['fused'][0] < best['jac'][0]*0.99 - 3e-4
     entry = dict(options=options, fused_pays=bool(fused_pays),
+                 jac_via_fused=bool(jac_via_fused),
                  seed=dict(jac=geo['jac'], fused=geo['fused']),
                  measured_ms=measured, nodes=nodes,
                  device=torch.cuda.get_device_name(dev), problem_sha=sha)

@@ -378,6 +378,41 @@ def test_specialised_kernels_follow_the_parameter_map():
     check('parameter changed again')
 
 
+def test_plan_flags_route_the_entry_points(tmp_path, monkeypatch):
+    """What a launch plan measured decides which kernels an entry point
+    launches: ``"jac_via_fused": true`` -> ``jacobian(free)`` comes from the
+    fused kernel (its constraint values go to a scratch vector),
+    ``"fused_pays": false`` -> ``opty_hip_eval_con_jac`` issues ``opty_con``
+    and ``opty_jac``.  Same values either way (to rounding: other kernels),
+    instance tails included."""
+    import json
+    import opty_amd
+    from opty_amd import hip_backend as hb, launch_plan as lp
+    kw = problems.build('config2_pendulum_small')     # instance constraints
+    ref = opty_amd.ConstraintCollocator(**kw)
+    free = problems.make_free(ref.num_free, seed=9)
+    con0 = ref.generate_constraint_function()(free)
+    jac0 = np.array(ref.generate_jacobian_function()(free))
+    key = lp.key_of(ref._build_program(), ref._launch_blocks())
+    path = tmp_path/'plans.json'
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(path))
+    for flags in (dict(jac_via_fused=True, fused_pays=True),
+                  dict(jac_via_fused=False, fused_pays=False)):
+        path.write_text(json.dumps({key: dict(options={}, **flags)}))
+        col = opty_amd.ConstraintCollocator(**kw)
+        hip = col.hip
+        assert hip.desc['jac_via_fused'] == int(flags['jac_via_fused'])
+        assert hip.desc['fused_loses'] == int(not flags['fused_pays'])
+        jac = np.empty_like(jac0)
+        hip.eval_jac(free, jac, hb.HOST)
+        con, jac2 = np.empty_like(con0), np.empty_like(jac0)
+        hip.eval_con_jac(free, con, jac2, hb.HOST)
+        for got, want in ((jac, jac0), (jac2, jac0), (con, con0)):
+            np.testing.assert_allclose(got, want, rtol=1e-12,
+                                       atol=1e-12*np.abs(want).max())
+        hip.close()
+
+
 def test_stream_switch_orders_the_invariant_table():
     """A handle whose node-invariant table depends on ``free`` (unknown
     parameters, variable h), used alternately on two streams: every launch

@@ -42,12 +42,14 @@ def main():
         # "auto+specialize" / "<options>,specialize=1": parameter-specialised
         # kernels (ConstraintCollocator(specialize_parameters=True))
         special = 'specialize' in spec
+        determ = '+deterministic' in spec
         bare = spec.replace('+specialize', '').replace(',specialize=1', '') \
-            .replace('specialize=1', '')
+            .replace('specialize=1', '').replace('+deterministic', '')
         opts = None if bare in ('auto', '') else (
             EmitOptions() if bare == 'default' else parse(bare))
         col = opty_amd.ConstraintCollocator(
-            emit_options=opts, specialize_parameters=special, **kw)
+            emit_options=opts, specialize_parameters=special,
+            deterministic=determ, **kw)
         if not torch.cuda.is_available():
             hsaco, meta = col._build_code_object()      # prebuild only
             print(spec, hb.vgpr_spills(hsaco), flush=True)
