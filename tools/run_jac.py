@@ -14,7 +14,10 @@ what = {'jac': hb.EVAL_JAC, 'con': hb.EVAL_CON, 'fused': hb.EVAL_FUSED}[sys.argv
 # 'default': what a collocator builds by itself (launch plan, spill-free cut)
 opts = None if spec == 'default' else parse(spec)
 workload = os.environ.get('OPTY_WORKLOAD', 'config3_10link')
-col = opty_amd.ConstraintCollocator(emit_options=opts, **problems.build(workload))
+col = opty_amd.ConstraintCollocator(
+    emit_options=opts,
+    specialize_parameters=os.environ.get('OPTY_SPECIALIZE') == '1',
+    **problems.build(workload))
 hip = col.hip
 dev = torch.device('cuda:0')
 hip.use_torch_stream()
