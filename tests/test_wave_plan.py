@@ -125,7 +125,10 @@ def test_planned_module_parks_only_what_it_needs():
     plain, m2 = emit_module(prog, EmitOptions(chunk=16, groups=5, park=48,
                                               park_live=235),
                             node_blocks=782)
-    assert 'opty_park' not in plain and 'plans' not in m2
+    # (a wave may still be PLANNED -- evaluated cheapest-next -- without
+    # needing a single row)
+    assert 'opty_park(' not in plain
+    assert all(q['slots'] == 0 for q in m2.get('plans', []))
 
 
 def _order_model(order, nblk, sets, W=1):
