@@ -1793,8 +1793,8 @@ class Problem(object):
     The reference subclasses ``cyipopt.Problem``; ``cyipopt`` is imported
     lazily here so that the collocator, the callbacks and the bounds arrays
     work without IPOPT.  ``solve`` needs ``cyipopt``.  Extra keywords
-    ``device``, ``prune_zeros``, ``jacobian_layout``, ``deterministic`` and
-    ``verify_builds`` go to the collocator;
+    ``device``, ``prune_zeros``, ``jacobian_layout``, ``deterministic``,
+    ``verify_builds`` and ``specialize_parameters`` go to the collocator;
     ``jacobianstructure()`` always matches what ``jacobian(free)`` returns.
 
     ``prune_zeros=True`` is the recommended setting when IPOPT runs on the
@@ -1814,7 +1814,7 @@ class Problem(object):
                  bounds=None, show_compile_output=False, backend='hip',
                  eom_bounds=None, device=0, prune_zeros=False,
                  jacobian_layout='coo', deterministic=False,
-                 verify_builds=None):
+                 verify_builds=None, specialize_parameters=False):
         if not sm.Matrix(equations_of_motion).has(sm.Derivative):
             raise ValueError('No time derivatives are present. The equations '
                              'of motion must be ordinary differential '
@@ -1827,7 +1827,8 @@ class Problem(object):
             parallel, show_compile_output=show_compile_output,
             backend=backend, device=device, prune_zeros=prune_zeros,
             jacobian_layout=jacobian_layout, deterministic=deterministic,
-            verify_builds=verify_builds)
+            verify_builds=verify_builds,
+            specialize_parameters=specialize_parameters)
         self._bounds = bounds
         if eom_bounds is not None:
             bad = [k for k in eom_bounds
