@@ -123,7 +123,8 @@ class EmitOptions(object):
                  fold_instance=None, inline_uniform=None, dear_first=0,
                  cut=None, con_attach=None, forget=0, rotate=None,
                  work_live=None, inline_dynamic=None, order=None, trace=0,
-                 park=0, park_live=215, strips=None, fused_strips=None,
+                 park=0, park_live=215, park_spread=0, strips=None,
+                 fused_strips=None,
                  fused_order=None, deterministic=0):
         # 1: every wave prints the same operations for the same DAG node:
         # sin / cos of an argument whose other half exists anywhere in the
@@ -152,6 +153,12 @@ class EmitOptions(object):
         # registers.  0 = off
         self.park = int(park)
         self.park_live = int(park_live)
+        # 1: the flushes of chunks whose values are ready early (constants,
+        # cheap entries) are SPREAD over the wave's operation stream instead
+        # of issued as soon as they can be: a wave that evaluates a heavy
+        # strip and store-only strips (``'160:348+0:96+96:160'``) then issues
+        # its stores in the shadow of its own arithmetic
+        self.park_spread = int(park_spread)
         # profiling aid (never used by the product): every wave records its
         # start / end (wall_clock64, shader cycles), its strip and where it
         # ran behind the Jacobian values -- ``jac`` must hold
@@ -330,6 +337,7 @@ class EmitOptions(object):
                 (' trace=1' if self.trace else '') +
                 (' park=%d/%d' % (self.park, self.park_live)
                  if self.park else '') +
+                (' park_spread=1' if self.park_spread else '') +
                 ('' if not self.strips else ' strips=%s' % self.strips) +
                 ('' if not self.fused_strips
                  else ' fused_strips=%s' % self.fused_strips) +
@@ -615,7 +623,9 @@ class _WavePlan(object):
     (Belady): computed once, stored once, reloaded once per later use
     cluster."""
 
-    def __init__(self, dag, targets, chunks, is_leaf, budget, order=None):
+    def __init__(self, dag, targets, chunks, is_leaf, budget, order=None,
+                 spread=False):
+        self.spread = bool(spread)
         self.dag = d = dag
         self.targets = targets
         self.chunks = chunks            # chunk c -> list of target indices
@@ -678,12 +688,22 @@ class _WavePlan(object):
                 chunk_of[k] = c
         next_chunk = 0
 
-        def flush_ready():
+        # (spread: at most one flush per ``pace`` operations while there are
+        # operations left; everything that is still due at the end)
+        total_ops = len(self.need)
+        pace = max(1, total_ops//max(1, len(self.chunks))) \
+            if self.spread else 0
+        since = [pace]
+
+        def flush_ready(final=False):
             nonlocal next_chunk
             while next_chunk < len(self.chunks) and \
                     chunk_left[next_chunk] == 0:
+                if pace and not final and since[0] < pace:
+                    return
                 events.append(('chunk', next_chunk))
                 next_chunk += 1
+                since[0] = 0
 
         flush_ready()
         rest = list(work)
@@ -716,13 +736,16 @@ class _WavePlan(object):
                     if v is not None:
                         done.add(v)
                         donemask |= 1 << self.bit[v]
+                since[0] += 1
+                if pace:
+                    flush_ready()
             if self.targets[k][0] == 'c':
                 events.append(('con', k))
             finished[k] = True
             if k in chunk_of:
                 chunk_left[chunk_of[k]] -= 1
             flush_ready()
-        flush_ready()
+        flush_ready(final=True)
         assert next_chunk == len(self.chunks)
         return events
 
@@ -1390,7 +1413,8 @@ class _ModuleWriter(object):
         def is_leaf(i):
             return d.op[i] == ir.CONST or body.leaf(i) is not None
 
-        plan = _WavePlan(d, targets, chunks, is_leaf, self.o.park_live)
+        plan = _WavePlan(d, targets, chunks, is_leaf, self.o.park_live,
+                         spread=self.o.park_spread)
         self._park_rows = max(self._park_rows, plan.slots)
         self._plans.append(dict(strips=strips, order=plan.order,
                                 peak=plan.peak, slots=plan.slots,
