@@ -2820,8 +2820,14 @@ int load_rccl() {
     const char *names[] = {getenv("OPTY_HIP_RCCL_LIBRARY"), "librccl.so.1",
                            "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
+    // a copy that the process holds already (PyTorch bundles its own next
+    // to its HIP runtime) comes first: one RCCL, one HIP runtime
+    for (const char *n : {"librccl.so", "librccl.so.1"})
+        if (!getenv("OPTY_HIP_RCCL_LIBRARY") &&
+            (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD))) break;
     for (const char *n : names)
-        if (n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib && n && *n && (lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+            break;
     if (!lib)
         return fail("librccl.so could not be loaded (%s): node-sharded "
                     "problems need RCCL", dlerror());

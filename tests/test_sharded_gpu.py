@@ -668,3 +668,47 @@ def test_shard_to_host_moves_only_what_changed():
     assert (blk2[:, static] == blk2[0, static]).all()
     assert not np.array_equal(blk2[0, static], blk3[0, static])
     jac_host.close()
+
+
+@pytest.mark.parametrize('name', ['config2_pendulum_small',
+                                  'pend2_link_vardur_unkmass_small'])
+def test_sharded_collocator_through_the_library_communicator(name):
+    """``ShardedCollocator(comm=HipComm(...))`` in a world of one rank, inside a
+    process that also holds PyTorch (one RCCL, one HIP runtime):
+    ``broadcast_free`` and ``gather`` go through ``opty_hip_bcast_free`` /
+    ``opty_hip_gather_v`` -- own shard copied from the shard buffers (strided
+    constraint copy) or evaluated in place, instance tails by the root -- and
+    return the single-GPU collocator's vectors."""
+    import torch
+    import opty_amd
+    from opty_amd import hip_backend as hb
+    from opty_amd.sharded import ShardedCollocator
+    kw = problems.build(name)
+    comm = hb.HipComm(hb.HipComm.unique_id(), 0, 1, device=0)
+    assert (comm.rank, comm.world) == (0, 1)
+    sh = ShardedCollocator(rank=0, world_size=1, device='cuda:0', comm=comm,
+                           **kw)
+    ref = opty_amd.ConstraintCollocator(**kw)
+    free_h = problems.make_free(ref.num_free, seed=3,
+                                variable_duration=ref._variable_duration)
+    con0 = ref.generate_constraint_function()(free_h)
+    jac0 = np.array(ref.generate_jacobian_function()(free_h))
+    free = torch.from_numpy(free_h).cuda()
+    assert sh.broadcast_free(free, 0) is free
+    for in_place in (False, True):
+        for what in ('both', 'con', 'jac'):
+            sh.evaluate(free, in_place=in_place, what=what)
+            con, jac = sh.gather(0, what)
+            torch.cuda.synchronize()
+            if what != 'jac':
+                np.testing.assert_allclose(
+                    con.cpu().numpy(), con0, rtol=1e-12,
+                    atol=1e-12*np.abs(con0).max())
+            if what != 'con':
+                np.testing.assert_allclose(
+                    jac.cpu().numpy(), jac0, rtol=1e-12,
+                    atol=1e-12*np.abs(jac0).max())
+    # misuse is reported through the C ABI's error channel
+    with pytest.raises(hb.HipBackendError, match='root'):
+        comm.bcast_free(sh.collocator.hip, free, root=5)
+    comm.close()
