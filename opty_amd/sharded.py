@@ -574,8 +574,44 @@ class ShardedCollocator(object):
         full equation-major constraint vector and node-major Jacobian value
         vector there, instance tails included (device tensors owned by this
         object, overwritten by the next call; the one ``what`` leaves out is
-        None), ``None`` on the other ranks."""
+        None), ``None`` on the other ranks.  With a :attr:`comm` the exchange
+        is the C ABI's ``opty_hip_gather_v`` (grouped ``ncclSend`` /
+        ``ncclRecv`` issued by the library on the handle's stream), otherwise
+        ``torch.distributed`` point-to-point."""
+        if self.comm is not None and self._hip_mode:
+            return self._gather_v(dst, what)
         return self._exchange([dst], what)
+
+    def _gather_v(self, dst, what):
+        from . import hip_backend as hb
+        sel = {'both': hb.EVAL_PAIR, 'con': hb.EVAL_CON,
+               'jac': hb.EVAL_JAC}[what]
+        want_con, want_jac = what != 'jac', what != 'con'
+        bounds = [a for a, _ in self.ranges] + [self.ranges[-1][1]]
+        self._use_stream()
+        hip = self.collocator.hip
+        if self.rank != dst:
+            src_con, src_jac = (self._own_views(what) if self._in_place
+                                else (self.con_local, self.jac_local))
+            if self._in_place and want_con:
+                # the constraint shard inside the global vector is strided:
+                # a message is dense
+                self.con_local.copy_(src_con)
+                src_con = self.con_local
+            self.comm.gather_v(hip, bounds, src_con if want_con else None,
+                               src_jac if want_jac else None, None, None,
+                               dst, sel)
+            return None
+        con_g, jac_g = self._global_buffers(what)
+        if self.o:
+            self.evaluate_instance(None, what, in_place=True)
+        own = (None, None) if self._in_place else (
+            self.con_local if want_con else None,
+            self.jac_local if want_jac else None)
+        self.comm.gather_v(hip, bounds, own[0], own[1],
+                           con_g if want_con else None,
+                           jac_g if want_jac else None, dst, sel)
+        return con_g, jac_g
 
     def all_gather(self):
         """The full vectors on every rank."""
