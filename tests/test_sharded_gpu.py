@@ -712,3 +712,44 @@ def test_sharded_collocator_through_the_library_communicator(name):
     with pytest.raises(hb.HipBackendError, match='root'):
         comm.bcast_free(sh.collocator.hip, free, root=5)
     comm.close()
+
+
+def _fake_rccl(tmp_path):
+    """Builds the test transport (``tests/fake_rccl``: librccl's entry points
+    over /dev/shm, so that several ranks can share one GPU)."""
+    lib = str(tmp_path/'libfake_rccl.so')
+    src = os.path.join(REPO, 'tests', 'fake_rccl', 'fake_rccl.cpp')
+    proc = subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared',
+                           '-fPIC', '-O1', src, '-o', lib],
+                          capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    return lib
+
+
+@pytest.mark.parametrize('name,world,root', [
+    ('config2_pendulum_small', 2, 0),           # instance constraints
+    ('pend2_link_vardur_unkmass_small', 3, 1),  # unknown parameters, free h
+    ('config3_10link_small', 3, 2)])            # 40 nodes: shards 14/13/13
+def test_gather_v_with_several_ranks(name, world, root, tmp_path):
+    """``opty_hip_bcast_free`` / ``opty_hip_gather_v`` with 2 and 3 ranks --
+    what RCCL cannot be asked for on a 1-GPU box (it refuses duplicate
+    devices): the library is pointed at a test transport with librccl's
+    entry points (``OPTY_HIP_RCCL_LIBRARY``), every rank runs
+    ``ShardedCollocator(comm=HipComm(...))`` on ``cuda:0``.  Checked on the
+    root against the single-GPU collocator: the broadcast free vector,
+    gathers of both / constraints only / Jacobian only, own shard copied or
+    evaluated in place, unequal shards, instance tails, a root that is not
+    rank 0."""
+    lib = _fake_rccl(tmp_path)
+    env = dict(os.environ, OPTY_HIP_RCCL_LIBRARY=lib)
+    idfile = str(tmp_path/'comm.id')
+    procs = [subprocess.Popen(
+        [sys.executable, os.path.join(REPO, 'tests', 'comm_worker.py'), name,
+         str(r), str(world), str(root), idfile],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, 'rank %d:\n%s' % (r, out[-3000:])
+        assert 'rank %d of %d ok' % (r, world) in out
+    assert '6 gathers checked' in outs[root]
