@@ -615,6 +615,9 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, 'launch with torch.distributed.run'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # ONE node by contract: RCCL's bootstrap socket on the loopback
+        # interface, not whichever the container has (data goes over xGMI)
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
         if oversub:
             dist.init_process_group('gloo')
         else:

@@ -138,8 +138,11 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     src_tmp = base + tag + '.hip'
     with open(src_tmp, 'w') as f:
         f.write(source)
-    cmd = [_hipcc()] + flags + ['--genco', '-I', CSRC, src_tmp, '-o',
-                                hsaco + tag]
+    # compressed offload bundle (zstd; hipModuleLoad and the bundler read it
+    # as they read a plain one): 4x smaller in the in-tree cache that travels
+    # with every GPU lease.  Not part of the digest: the code is the same.
+    cmd = [_hipcc()] + flags + list(COMPRESS_FLAGS) + [
+        '--genco', '-I', CSRC, src_tmp, '-o', hsaco + tag]
     logger.info('compiling %s', base + '.hip')
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if show_compile_output:
@@ -162,6 +165,10 @@ def compile_module(source, cache_dir=None, show_compile_output=False,
     os.replace(hsaco + tag, hsaco)
     return hsaco
 
+
+#: how a code object is stored (OPTY_HIPCC_COMPRESS=0: plain bundles)
+COMPRESS_FLAGS = () if os.environ.get('OPTY_HIPCC_COMPRESS') == '0' else (
+    '--offload-compress', '--offload-compression-level=19')
 
 #: hipcc switches of the last-resort build of a module whose kernels spill
 #: vector registers whatever the cut: without the scheduler stage that the

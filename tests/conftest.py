@@ -8,6 +8,11 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 
+# every RCCL bootstrap of this suite is within one box: loopback, not
+# whichever interface the container happens to have (tests/test_c_client.py)
+os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
