@@ -64,6 +64,9 @@ enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
 #define OPTY_HIP_LAYOUT_CSR 1
 #define OPTY_HIP_LAYOUT_SEGMENTED 2
 
+/* strip classes a list schedule can hold (opty_hip_desc.jac_class_cost) */
+#define OPTY_HIP_MAX_CLASSES 32
+
 typedef struct opty_hip_desc {
     int64_t N;            /* collocation (time) nodes                        */
     int32_t n;            /* states                                          */
@@ -113,15 +116,45 @@ typedef struct opty_hip_desc {
                              stream): OPTY_HIP_EVAL_JAC launches the fused
                              kernel, its constraint values go to a scratch
                              vector of the handle                            */
+    int32_t jac_persist;  /* > 0: opty_jac is a persistent kernel with a list
+                             schedule: launched with at most this many
+                             one-wave workgroups (a multiple of 8; 1024 = one
+                             per SIMD), each of which evaluates a list of
+                             (node block, strip class) items that the library
+                             computes per launch size -- longest class first
+                             onto the least loaded workgroup of the block's
+                             XCD -- from the class costs below.  A launch of
+                             waves that each hold a SIMD alone then costs
+                             about sum(wave durations) / 1024, without the idle
+                             time a one-wave-per-item dispatch leaves between
+                             and after the waves                              */
+    int32_t fused_persist; /* the same for opty_conjac                        */
+    float jac_class_cost[OPTY_HIP_MAX_CLASSES];   /* relative duration of the
+                             wave of strip class g (any unit; measured by the
+                             launch plan's tuner or the printer's estimate);
+                             classes = jac_wgs_per_block                      */
+    float fused_class_cost[OPTY_HIP_MAX_CLASSES];
 } opty_hip_desc;
 
 /* Version of this header's structs and signatures; opty_hip_abi_version()
  * returns the one the library was built from.  A client built against another
- * version must not call the library: the descriptor grew in 5, and
+ * version must not call the library: the descriptor grew in 5 and 6, and
  * opty_hip_eval_jac_persistent / opty_hip_shard_jac_to_host took their `fresh`
  * argument in 4. */
-#define OPTY_HIP_ABI_VERSION 5
+#define OPTY_HIP_ABI_VERSION 6
 int opty_hip_abi_version(void);
+
+/* The list schedule the library gives a persistent kernel (opty_hip_desc.
+ * jac_persist / fused_persist) for a launch over `node_blocks` 64-node blocks
+ * with `classes` strip classes of relative duration class_cost[g]: host
+ * arithmetic only (inspection, tests).  table[0] = workgroups npw;
+ * table[1 .. npw + 1] = first item of workgroup w (workgroup w serves XCD
+ * w % 8); table[npw + 2 ...] = items, (class << 24) | s for node block
+ * 8 s + XCD, every workgroup's in the order in which it evaluates them.
+ * `table` may be null (count only). */
+int opty_hip_list_schedule(int persist, int64_t node_blocks, int classes,
+                           const float *class_cost, int32_t *table,
+                           int64_t capacity, int64_t *count);
 
 /* Loads the code object and allocates the device-side state (known
  * parameters, known trajectories, staging buffers). */

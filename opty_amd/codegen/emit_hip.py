@@ -62,6 +62,8 @@ UNI_WORKGROUPS = 16
 #: waves an MI355X holds at once when a CU takes four of these kernels' waves
 #: (256 CUs x 4 SIMDs; one wave per SIMD at their register footprint)
 RESIDENT_WAVES = 1024
+#: strip classes a list schedule can hold (OPTY_HIP_MAX_CLASSES)
+MAX_CLASSES = 32
 #: entries of a node's block one wave of opty_jac takes when registers do not
 #: ask for fewer (~50 KB of output per wave and 64-node block), at most 32
 #: waves.  Interleaved A/B timings on MI355X after coefficient collection made
@@ -107,6 +109,28 @@ KERNEL_PARAMS = (
     'long long node_end')
 
 
+_LOOP_HELPERS = '''\
+// Values the optimiser must take as new in every iteration of a persistent
+// kernel's item loops (see the kernels).
+template <typename T>
+__device__ __forceinline__ T *opty_opaque(T *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ long long opty_opaque(long long x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ double opty_opaque(double x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ int opty_opaque_lane(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}'''
+
+
 class EmitOptions(object):
     """Knobs of the printer.
 
@@ -125,7 +149,13 @@ class EmitOptions(object):
                  work_live=None, inline_dynamic=None, order=None, trace=0,
                  park=0, park_live=215, park_spread=0, strips=None,
                  fused_strips=None,
-                 fused_order=None, deterministic=0):
+                 fused_order=None, deterministic=0, class_cost=None,
+                 fused_class_cost=None):
+        # relative wave durations of the strip classes of a persistent kernel
+        # ('20.5;11.6;4.7': measured by a traced launch) for its list
+        # schedule; None: the printer's estimate
+        self.class_cost = class_cost
+        self.fused_class_cost = fused_class_cost
         # 1: every wave prints the same operations for the same DAG node:
         # sin / cos of an argument whose other half exists anywhere in the
         # DAG always come from one ``sincos`` (not from ``sin`` alone in the
@@ -135,7 +165,7 @@ class EmitOptions(object):
         self.deterministic = int(deterministic)
         # the same two choices for opty_conjac alone (None: as opty_jac's)
         self.fused_strips = fused_strips
-        assert fused_order in (None, 'block', 'class', 'tail')
+        assert fused_order in (None, 'block', 'class', 'tail', 'list')
         self.fused_order = fused_order
         # explicit cut of a node-major block (experiments, plan files):
         # ``'96:160;160:348+0:96'`` = two waves, the second one with two
@@ -178,7 +208,7 @@ class EmitOptions(object):
         # dispatched class by class -- their long waves first, the short
         # ones last: a launch in 'block' order ends with the long waves of
         # its last blocks running alone
-        assert order in (None, 'block', 'class', 'tail')
+        assert order in (None, 'block', 'class', 'tail', 'list')
         self.order = order
         # 1: a strip's temporaries are dropped at every chunk boundary and
         # recomputed where needed again (bounded register pressure; the last
@@ -1692,6 +1722,83 @@ class _ModuleWriter(object):
     (void)ncn;
 '''
 
+    # order == 'list': a persistent kernel.  At most RESIDENT_WAVES one-wave
+    # workgroups (one per SIMD: these waves hold one alone), each evaluates
+    # the list of (block, strip class) items that the runtime's list schedule
+    # gives it (``sched``, one more kernel parameter: csrc/opty_hip.cpp
+    # build_schedule) -- instead of one workgroup per item, dispatched by the
+    # hardware as SIMDs fall idle.
+    _LIST_HEAD = '''\
+    const int lane_o = threadIdx.x & 63;
+    const int wave = 0;
+    const long long nblk = (node_end - node_begin + 63)/64;
+    const long long xcd = blockIdx.x & 7;
+    const int npw = sched[0];
+'''
+    _LIST_LOOP = '''\
+    const int *const items = sched + 2 + npw;
+    int it = sched[1 + blockIdx.x];
+    const int it_end = sched[2 + blockIdx.x];
+    int item = it < it_end ? items[it] : -1;
+    const double h_o = h;
+    const long long N_o = N, stride_o = con_stride, begin_o = node_begin,
+        end_o = node_end;
+'''
+    # Inside the loops every kernel argument and the lane number are re-defined
+    # through an empty ``asm volatile``: to the compiler nothing an item
+    # computes is loop-invariant.  Otherwise it hoists what the strips derive
+    # from them -- scalar loads of parameters and table values, row addresses,
+    # per-lane LDS addresses -- out of the loop, where it stays live through
+    # every item: hundreds of spilled SGPRs in VGPR lanes and spilled VGPRs in
+    # kernels that have no register to spare (biped: 58 -> 390 SGPR spills,
+    # 0 -> 77 spilled VGPRs).  The modules are built without MachineLICM for
+    # the same reason (materialised constants).  (Pointers: the kernel's own
+    # ``__restrict__`` parameters plus an opaque zero -- a pointer that went
+    # through the asm itself would lose what lets the parameter loads be
+    # scalar loads.)
+    _LIST_ITEM = '''\
+    while (item >= 0) {{
+    const long long blk = (long long)(item & 0xffffff)*8 + xcd;
+    const int grp = item >> 24;
+    ++it;
+    const int item_next = it < it_end ? items[it] : -1;
+    const long long opq = opty_opaque(0LL);
+    const double *const free_i = free_ + opq, *const known_i = known_traj + opq;
+    const double *const params_i = params + opq, *const uni_i = uni_c + opq;
+    const long long *const inst_i = inst_idx + opq;
+    double *const con_i = con + opq, *const jac_i = jac + opq;
+    {{
+    const double *const free_ = free_i, *const known_traj = known_i;
+    const double *const params = params_i, *const uni_c = uni_i;
+    const long long *const inst_idx = inst_i;
+    double *const con = con_i, *const jac = jac_i;
+    const double h = opty_opaque(h_o);
+    const long long N = opty_opaque(N_o), con_stride = opty_opaque(stride_o);
+    const long long node_begin = opty_opaque(begin_o);
+    const long long node_end = opty_opaque(end_o);
+    const int lane = opty_opaque_lane(lane_o);
+    (void)known_traj; (void)params; (void)uni_c; (void)inst_idx; (void)con;
+    (void)h; (void)con_stride;
+    if (blk < nblk) {{
+    const long long node0 = node_begin + blk*64;
+    const long long node = node0 + lane;
+    const bool valid = node < node_end;
+    const long long rem = node_end - node0;
+    const int nvalid = rem < 64 ? (int)rem : 64;
+    const long long ncn = node_end - node_begin, nloc = node0 - node_begin;
+    double *jrow = jac + nloc*{P}LL;
+    double *const ring = lds + {slab} + wave*{ring};
+    (void)valid; (void)jrow; (void)nvalid; (void)node; (void)ring; (void)grp;
+    (void)ncn;
+'''
+    _LIST_NEXT = '''\
+    }
+    }
+    opty_wave_sync();
+    item = item_next;
+    }
+'''
+
     def kernel(self, name, groups, con_of_group, W=1, con_nt=False,
                inst_lines=None, first_group=0, order=None):
         """One kernel.  ``groups`` = one list of entry strips ``(e0, e1)`` per
@@ -1730,6 +1837,11 @@ class _ModuleWriter(object):
             else:
                 W = self._waves_per_workgroup(len(rows), ring_rows)
         W = max(1, min(W, G))
+        order = order or self.o.order
+        listed = order == 'list' and G <= MAX_CLASSES and any(
+            e1 > e0 for grp in groups for e0, e1 in grp)
+        if listed:
+            W = 1
         # a hand-set workgroup width that does not fit the CU's LDS (64-entry
         # chunks of a 4-wave workgroup next to a large slab) is narrowed
         # instead of failing in hipcc ("local memory exceeds limit")
@@ -1761,10 +1873,14 @@ class _ModuleWriter(object):
             self.o.occupancy, self.o.occupancy) if self.o.occupancy else ''
         src = ['extern "C" __global__ void __launch_bounds__(%d)%s'
                % (64*W, occ),
-               '%s(%s)' % (name, KERNEL_PARAMS), '{',
+               '%s(%s)' % (name, KERNEL_PARAMS + (
+                   ', const int *__restrict__ sched' if listed else '')), '{',
                '    __shared__ double lds[%d];' % lds_doubles]
+        if listed:
+            src += [self._LIST_HEAD]
         if inst_lines:
-            src += ['    if (blockIdx.x >= ((node_end - node_begin + 63)/64 + '
+            src += ['    if (blockIdx.x >= npw) {' if listed else
+                    '    if (blockIdx.x >= ((node_end - node_begin + 63)/64 + '
                     '7)/8*8*%d) {' % sets,
                     '        if (threadIdx.x == 0) {']
             src += ['            ' + ln for ln in inst_lines]
@@ -1783,7 +1899,6 @@ class _ModuleWriter(object):
             # biped's Jacobian kernel with 4 work-aware strips: 0.104 ms,
             # with 5: 0.066 ms).
             rot = '(%s + slot/%d)' % (rot, sets)
-        order = order or self.o.order
         if order == 'tail' and sets > 1:
             # block by block, then the last ``tail`` blocks of every XCD
             # class by class (sets sorted longest first)
@@ -1809,9 +1924,14 @@ class _ModuleWriter(object):
             mapping = ('const long long blk = (slot/{sets})*8 + xcd;\n'
                        '    const int grp = (int)({rot} % {sets})*{W} + wave;'
                        ).format(sets=sets, W=W, rot=rot)
-        src += [self._PROLOGUE.format(P=self.p.P, mapping=mapping,
-                                      slab=len(rows)*TS, ring=ring_rows*TS)]
-        if park_rows:
+        if not listed:
+            src += [self._PROLOGUE.format(P=self.p.P, mapping=mapping,
+                                          slab=len(rows)*TS,
+                                          ring=ring_rows*TS)]
+        if park_rows and listed:
+            src.append('    double *const park_o = lds + %d;'
+                       % ((len(rows) + rings*ring_rows)*TS))
+        elif park_rows:
             # the wave's parking rows (behind the ring tiles); reloads go
             # through ``lane_z`` == lane, which the compiler cannot prove, so
             # that it neither forwards the parked value from its register
@@ -1819,13 +1939,35 @@ class _ModuleWriter(object):
             src += ['    double *const park = lds + %d + wave*%d;'
                     % ((len(rows) + rings*ring_rows)*TS, park_rows*WAVE),
                     '    const int lane_z = lane + (int)(N >> 62);']
-        if self.o.trace:
-            src += ['    const long long tr_w0 = wall_clock64();',
-                    '    const long long tr_c0 = __builtin_readcyclecounter();']
-        src += ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
-        if G == 1:
-            src += ['    ' + ln for ln in bodies[0]]
-        else:
+        trace_head = [
+            '    const long long tr_w0 = wall_clock64();',
+            '    const long long tr_c0 = __builtin_readcyclecounter();'] \
+            if self.o.trace else []
+        trace_tail = [
+            '    if (lane == 0 && jac) {',
+            '        long long *tr = reinterpret_cast<long long *>(jac + '
+            'ncn*%dLL + %d) + ((long long)%s*%d + wave)*4;'
+            % (self.p.P, TRACE_OFFSET,
+               '(((long long)(item & 0xffffff)*%d + grp)*8 + xcd)' % sets
+               if listed else 'blockIdx.x', W),
+            '        tr[0] = tr_w0; tr[1] = wall_clock64();',
+            '        tr[2] = ((long long)grp << 40) | blk;',
+            '        tr[3] = ((long long)(__builtin_readcyclecounter() - '
+            'tr_c0) << 24) | (long long)(__builtin_amdgcn_s_getreg('
+            'GETREG_IMMED(3, 0, 20)) << 16) | (long long)'
+            '__builtin_amdgcn_s_getreg(GETREG_IMMED(15, 0, 4));',
+            '    }'] if self.o.trace else []
+        fill = ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
+        if listed:
+            # one loop around the switch: items in the order of the schedule
+            src += [self._LIST_LOOP,
+                    self._LIST_ITEM.format(P=self.p.P, slab=len(rows)*TS,
+                                           ring=ring_rows*TS)]
+            if park_rows:
+                src += ['    double *const park = park_o;',
+                        '    const int lane_z = lane + (int)(N >> 62);',
+                        '    (void)park; (void)lane_z;']
+            src += trace_head + fill
             src.append('    switch (grp) {')
             for g, lines in enumerate(bodies):
                 src.append('    case %d: {' % g)
@@ -1833,19 +1975,20 @@ class _ModuleWriter(object):
                 src.append('    } break;')
             src.append('    default: break;')
             src.append('    }')
-        if self.o.trace:
-            src += [
-                '    if (lane == 0 && jac) {',
-                '        long long *tr = reinterpret_cast<long long *>(jac + '
-                'ncn*%dLL + %d) + ((long long)blockIdx.x*%d + wave)*4;'
-                % (self.p.P, TRACE_OFFSET, W),
-                '        tr[0] = tr_w0; tr[1] = wall_clock64();',
-                '        tr[2] = ((long long)grp << 40) | blk;',
-                '        tr[3] = ((long long)(__builtin_readcyclecounter() - '
-                'tr_c0) << 24) | (long long)(__builtin_amdgcn_s_getreg('
-                'GETREG_IMMED(3, 0, 20)) << 16) | (long long)'
-                '__builtin_amdgcn_s_getreg(GETREG_IMMED(15, 0, 4));',
-                '    }']
+            src += trace_tail + [self._LIST_NEXT]
+        else:
+            src += trace_head + fill
+            if G == 1:
+                src += ['    ' + ln for ln in bodies[0]]
+            else:
+                src.append('    switch (grp) {')
+                for g, lines in enumerate(bodies):
+                    src.append('    case %d: {' % g)
+                    src += ['        ' + ln for ln in lines]
+                    src.append('    } break;')
+                src.append('    default: break;')
+                src.append('    }')
+            src += trace_tail
         src.append('}')
         text = '\n'.join(src)
         # sha of this kernel's own source: profiles/traffic.json keys the PMC
@@ -1854,7 +1997,23 @@ class _ModuleWriter(object):
         return text, dict(name=name, groups=G, waves_per_wg=W,
                           wgs_per_block=sets, lds_bytes=lds_doubles*8,
                           park_rows=park_rows,
+                          persist=RESIDENT_WAVES if listed else 0,
+                          class_cost=self._given_cost(name, G) or [
+                              float(sum(self._weighted_cost(e0, e1) +
+                                        STORE_WEIGHT*(e1 - e0)
+                                        for e0, e1 in grp if e1 > e0) +
+                                    60*len(con_of_group[g]) + 100)
+                              for g, grp in enumerate(groups)]
+                          if listed else [],
                           sha=hashlib.sha256(text.encode()).hexdigest())
+
+    def _given_cost(self, name, G):
+        given = self.o.fused_class_cost if name == 'opty_conjac' \
+            else self.o.class_cost
+        if not given:
+            return None
+        cost = [float(c) for c in str(given).split(';')]
+        return cost if len(cost) == G else None
 
     @staticmethod
     def _waves_per_workgroup(slab_rows, ring_rows, lds_per_cu=160*1024):
@@ -2311,9 +2470,9 @@ def emit_module(prog, opts=None, node_blocks=None, literals=None):
         def work(grp):
             return sum(w._weighted_cost(e0, e1) + STORE_WEIGHT*(e1 - e0)
                        for e0, e1 in grp if e1 > e0)
-        if opts.order in ('class', 'tail'):
+        if opts.order in ('class', 'tail', 'list'):
             groups = sorted(groups, key=work, reverse=True)
-        if (opts.fused_order or opts.order) in ('class', 'tail'):
+        if (opts.fused_order or opts.order) in ('class', 'tail', 'list'):
             fused_jac = sorted(fused_jac, key=work, reverse=True)
     # The fused kernel is the Jacobian kernel plus the constraint waves (empty
     # entry ranges): the Jacobian waves keep their register budget, the extra
@@ -2375,6 +2534,8 @@ def emit_module(prog, opts=None, node_blocks=None, literals=None):
             '#include "opty_device.h"', '']
     if getattr(w, 'uses_park', False):
         head += [_PARK_HELPERS, '']
+    if any(k.get('persist') for k in kernels.values()):
+        head += [_LOOP_HELPERS, '']
     source = '\n'.join(head + parts)
     meta = dict(kernels=kernels,
                 groups=[[list(rg) for rg in grp] for grp in groups],

@@ -21,10 +21,12 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <queue>
 #include <string>
 #include <thread>
 #include <utility>
@@ -75,6 +77,9 @@ struct KernelArgs {
     long long con_stride;
     long long node_begin;
     long long node_end;
+    // kernels with a list schedule only (desc.jac_persist / fused_persist):
+    // one more parameter, the schedule table (build_schedule below)
+    const int *sched;
 };
 
 // ---------------------------------------------------------------------------
@@ -650,7 +655,16 @@ private:
 
 }  // namespace
 
+// one list schedule of a persistent kernel (build_schedule below), on the
+// device: per launch size
+struct Schedule {
+    long long nblk = -1;
+    int *d_table = nullptr;
+    int npw = 0;
+};
+
 struct opty_hip_problem {
+    std::vector<Schedule> sched_jac, sched_fused;
     opty_hip_desc d{};
     hipModule_t module = nullptr;
     hipFunction_t k_con = nullptr, k_jac = nullptr, k_conjac = nullptr,
@@ -765,9 +779,76 @@ int order_streams(Handle *p) {
 // The launch evaluates the constraint nodes [begin, end) of the handle's
 // problem: `con` points at the shard's first value of equation 0 (equations
 // are `con_stride` doubles apart), `jac` at the shard's first block.
+// List schedule of a persistent kernel (dispatch order 'list' of the printer):
+// `npw` one-wave workgroups -- workgroup w runs on XCD w % 8 and holds a SIMD
+// alone -- share the (node block, strip class) items of a launch; class g of
+// every block takes cost[g] (any unit).  Per XCD: longest processing time
+// first onto the least loaded workgroup, so that a launch costs about
+// sum(durations) / npw instead of what the hardware's one-wave-per-item
+// dispatch leaves idle between and after the waves.  Table:
+//   [0] npw   [1 .. npw + 1] item offsets per workgroup   [npw + 2 ..] items,
+// an item = (class << 24) | block slot s of the XCD (block = 8 s + XCD), in the
+// order in which the workgroup evaluates them.
+std::vector<int> build_schedule(int persist, long long nblk, int sets,
+                                const float *cost) {
+    static const bool rotate = !getenv("OPTY_HIP_LIST_NO_ROTATE");
+    const long long nslot = (nblk + 7)/8;
+    long long total = nslot*8*sets;
+    const int npw = (int)(total < persist ? total : persist);
+    const int bins = npw/8;
+    std::vector<std::vector<int>> mine((size_t)npw);
+    // classes, longest first (stable: the printer sorted them already)
+    std::vector<int> order((size_t)sets);
+    for (int g = 0; g < sets; ++g) order[(size_t)g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return cost[a] > cost[b];
+    });
+    for (int x = 0; x < 8 && bins > 0; ++x) {
+        typedef std::pair<double, int> Load;        // (load, workgroup slot)
+        std::priority_queue<Load, std::vector<Load>, std::greater<Load>> q;
+        for (int j = 0; j < bins; ++j) q.push(Load(0.0, j));
+        for (int g : order) {
+            const double c = cost[g] > 0.f ? cost[g] : 1.0;
+            for (long long s = 0; s < nslot; ++s) {
+                if (s*8 + x >= nblk) break;
+                Load l = q.top();
+                q.pop();
+                mine[(size_t)(l.second*8 + x)].push_back((g << 24) | (int)s);
+                l.first += c;
+                q.push(l);
+            }
+        }
+    }
+    std::vector<int> table;
+    table.push_back(npw);
+    int at = 0;
+    for (int w = 0; w < npw; ++w) {
+        table.push_back(at);
+        // Every workgroup starts somewhere else in its list (longest first,
+        // rotated by its number): the short, store-heavy strips of a launch
+        // then run spread over its whole duration, next to the long ones --
+        // all of them at its end, they queue for the memory system (biped:
+        // 700 concurrent store-only waves took 13.9 us instead of 8.4)
+        std::vector<int> &m = mine[(size_t)w];
+        if (rotate && m.size() > 1)
+            std::rotate(m.begin(), m.begin() + (w/8) % (int)m.size(), m.end());
+        at += (int)m.size();
+    }
+    table.push_back(at);
+    for (int w = 0; w < npw; ++w)
+        table.insert(table.end(), mine[(size_t)w].begin(),
+                     mine[(size_t)w].end());
+    return table;
+}
+
+// persist > 0: a persistent kernel with a list schedule (`sched`: the
+// handle's cache of tables, one per launch size); at most `persist`
+// workgroups.
 int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
            int threads, const double *free_, double *con, double *jac,
-           const NodeRange &rg, bool inst_block = false) {
+           const NodeRange &rg, bool inst_block = false, int persist = 0,
+           std::vector<Schedule> *sched = nullptr,
+           const float *cost = nullptr) {
     KernelArgs a;
     a.free_ = free_;
     a.known_traj = p->d_known;
@@ -783,7 +864,39 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
     a.con_stride = rg.con_stride;
     a.node_begin = rg.begin;
     a.node_end = rg.end;
-    size_t size = sizeof a;
+    a.sched = nullptr;
+    size_t size = offsetof(KernelArgs, sched);
+    int npw = 0;
+    if (persist > 0 && wgs_per_block > 0) {
+        const long long nblk = (rg.end - rg.begin + 63)/64;
+        if (nblk == 0) return 0;
+        Schedule *hit = nullptr;
+        for (Schedule &sc : *sched)
+            if (sc.nblk == nblk) hit = &sc;
+        if (!hit) {
+            // first launch of this size: build and upload (synchronous)
+            std::vector<int> table =
+                build_schedule(persist, nblk, wgs_per_block, cost);
+            Schedule sc;
+            sc.nblk = nblk;
+            sc.npw = table[0];
+            HIP_TRY(hipMalloc((void **)&sc.d_table,
+                              table.size()*sizeof(int)));
+            HIP_TRY(hipMemcpy(sc.d_table, table.data(),
+                              table.size()*sizeof(int),
+                              hipMemcpyHostToDevice));
+            if (sched->size() >= 16) {          // shard sizes come and go
+                (void)hipStreamSynchronize(sync_target(p->stream));
+                (void)hipFree(sched->front().d_table);
+                sched->erase(sched->begin());
+            }
+            sched->push_back(sc);
+            hit = &sched->back();
+        }
+        a.sched = hit->d_table;
+        npw = hit->npw;
+        size = sizeof a;
+    }
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a,
                       HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
                       HIP_LAUNCH_PARAM_END};
@@ -796,7 +909,11 @@ int launch(opty_hip_problem *p, hipFunction_t f, int wgs_per_block,
         const long long nblk = ((rg.end - rg.begin + 63)/64 + 7)/8*8;
         // inst_block: one more workgroup, which evaluates the instance-
         // constraint tails (modules built with desc.inst_folded)
-        grid = (unsigned)(nblk*wgs_per_block) + (inst_block ? 1u : 0u);
+        grid = (unsigned)(nblk*wgs_per_block);
+        // (a persistent kernel reads the same number from its table: the
+        // workgroup behind them evaluates the instance tails)
+        if (persist > 0) grid = (unsigned)npw;
+        grid += inst_block ? 1u : 0u;
         if (grid == 0) return 0;
     }
     HIP_TRY(hipModuleLaunchKernel(f, grid, 1, 1, threads, 1, 1, 0, p->stream,
@@ -851,7 +968,9 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
         NodeRange sr{rg.begin, rg.end, p->ncon_nodes()};
         if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
                             64*p->d.fused_waves_per_wg, free_,
-                            p->d_con_scratch + rg.begin, jac, sr, folded))
+                            p->d_con_scratch + rg.begin, jac, sr, folded,
+                            p->d.fused_persist, &p->sched_fused,
+                            p->d.fused_class_cost))
             return rc;
         if (tails && !folded)
             if (int rc = launch_instance(
@@ -866,12 +985,14 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
             return rc;
     if (what == OPTY_HIP_EVAL_JAC || what == OPTY_HIP_EVAL_PAIR)
         if (int rc = launch(p, p->k_jac, S, T, free_, nullptr, jac, rg,
-                            folded))
+                            folded, p->d.jac_persist, &p->sched_jac,
+                            p->d.jac_class_cost))
             return rc;
     if (what == OPTY_HIP_EVAL_FUSED)
         if (int rc = launch(p, p->k_conjac, p->d.fused_wgs_per_block,
                             64*p->d.fused_waves_per_wg, free_, con, jac, rg,
-                            folded))
+                            folded, p->d.fused_persist, &p->sched_fused,
+                            p->d.fused_class_cost))
             return rc;
     if (tails && !folded) {
         double *c = (what == OPTY_HIP_EVAL_JAC) ? nullptr
@@ -1505,6 +1626,25 @@ int opty_hip_host_free(void *ptr) {
 
 int opty_hip_abi_version(void) { return OPTY_HIP_ABI_VERSION; }
 
+int opty_hip_list_schedule(int persist, int64_t node_blocks, int classes,
+                           const float *class_cost, int32_t *table,
+                           int64_t capacity, int64_t *count) {
+    if (persist < 8 || persist % 8 || node_blocks < 0 || classes < 1 ||
+        classes > OPTY_HIP_MAX_CLASSES || !class_cost || !count)
+        return fail("bad list-schedule request (%d workgroups, %lld blocks, "
+                    "%d classes)", persist, (long long)node_blocks, classes);
+    std::vector<int> t = build_schedule(persist, node_blocks, classes,
+                                        class_cost);
+    *count = (int64_t)t.size();
+    if (table) {
+        if (capacity < (int64_t)t.size())
+            return fail("schedule table needs %lld words",
+                        (long long)t.size());
+        memcpy(table, t.data(), t.size()*sizeof(int));
+    }
+    return 0;
+}
+
 int opty_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1533,6 +1673,19 @@ int opty_hip_create(const opty_hip_desc *desc, const char *code_object_path,
         desc->con_waves_per_wg > 16)
         return fail("bad Jacobian launch geometry (%d workgroups x %d waves)",
                     desc->jac_wgs_per_block, desc->jac_waves_per_wg);
+    if (desc->jac_persist < 0 || desc->fused_persist < 0 ||
+        desc->jac_persist % 8 || desc->fused_persist % 8 ||
+        (desc->jac_persist && desc->jac_waves_per_wg != 1) ||
+        (desc->fused_persist && desc->fused_waves_per_wg != 1))
+        return fail("persistent kernels take a multiple of 8 one-wave "
+                    "workgroups (jac_persist %d, fused_persist %d)",
+                    desc->jac_persist, desc->fused_persist);
+    if ((desc->jac_persist &&
+         desc->jac_wgs_per_block > OPTY_HIP_MAX_CLASSES) ||
+        (desc->fused_persist &&
+         desc->fused_wgs_per_block > OPTY_HIP_MAX_CLASSES))
+        return fail("a list schedule takes at most %d strip classes",
+                    OPTY_HIP_MAX_CLASSES);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         return fail("no HIP device is visible: the HIP backend has no CPU "
@@ -1602,6 +1755,8 @@ int opty_hip_destroy(opty_hip_problem *p) {
                     p->d_dense, p->d_seg, p->d_con_scratch};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (auto *v : {&p->sched_jac, &p->sched_fused})
+        for (Schedule &sc : *v) (void)hipFree(sc.d_table);
     void *pinned[] = {p->h_packed, p->h_free, p->h_con, p->h_jac};
     for (void *b : pinned)
         if (b) (void)hipHostFree(b);

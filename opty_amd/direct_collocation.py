@@ -597,6 +597,9 @@ class ConstraintCollocator(object):
         ``deterministic`` collocator's without FMA contraction)."""
         if self._deterministic:
             extra_flags = tuple(extra_flags) + hb.DETERMINISTIC_FLAGS
+        if 'opty_opaque(' in source:
+            # modules with persistent kernels (dispatch order 'list')
+            extra_flags = tuple(extra_flags) + hb.LOOP_FLAGS
         return hb.compile_module(source, self.tmp_dir,
                                  self.show_compile_output,
                                  opt_level=opt_level,
@@ -1335,7 +1338,31 @@ class ConstraintCollocator(object):
                     'varying_first': 2}[self._jacobian_layout],
             inst_folded=int(meta.get('inst_folded', False)),
             fused_loses=self._fused_loses(),
-            jac_via_fused=self._plan_flag('jac_via_fused'))
+            jac_via_fused=self._plan_flag('jac_via_fused'),
+            jac_persist=meta['kernels']['jac'].get('persist', 0),
+            fused_persist=meta['kernels']['conjac'].get('persist', 0),
+            jac_class_cost=self._class_cost(meta, 'jac'),
+            fused_class_cost=self._class_cost(meta, 'conjac'))
+
+    def _class_cost(self, meta, key):
+        """Relative wave durations of a persistent kernel's strip classes
+        (``opty_hip_desc.*_class_cost``): measured ones from the launch plan
+        (``"jac_durations"`` / ``"fused_durations"``, recorded by the tuner
+        from a traced launch) when they fit the kernel, else the printer's
+        estimate."""
+        k = meta['kernels'][key]
+        if not k.get('persist'):
+            return ()
+        cost = list(k['class_cost'])
+        if self._emit_options is None:
+            from . import launch_plan
+            entry = launch_plan.lookup_entry(self._build_program(),
+                                             self._launch_blocks()) or {}
+            got = entry.get('fused_durations' if key == 'conjac'
+                            else 'jac_durations')
+            if got and len(got) == len(cost):
+                cost = list(got)
+        return tuple(float(c) for c in cost)
 
     def _fused_loses(self):
         """1 when the launch plan of this problem and launch size measured

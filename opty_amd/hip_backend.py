@@ -29,7 +29,7 @@ DEFAULT_CACHE = os.path.join(_PKG, '_cache')
 ARCH = 'gfx950'
 
 #: OPTY_HIP_ABI_VERSION of include/opty_hip.h these bindings were written for
-ABI_VERSION = 5
+ABI_VERSION = 6
 HOST, DEVICE = 0, 1
 #: hipStreamLegacy: the null / legacy default stream (torch's default)
 STREAM_LEGACY = 1
@@ -181,6 +181,12 @@ SAFE_SCHEDULER_FLAGS = ('-mllvm',
 #: entry's value does not depend on which wave's straight-line code holds it
 DETERMINISTIC_FLAGS = ('-ffp-contract=off',)
 
+#: hipcc switches of a module with persistent kernels (dispatch order 'list':
+#: loops over (block, strip) items): without MachineLICM, which would move
+#: the materialised constants of every strip out of the item loops and keep
+#: them alive (in spilled SGPRs) through all of them
+LOOP_FLAGS = ('-mllvm', '-disable-machine-licm')
+
 _RESOURCE_KEYS = ('.vgpr_count', '.agpr_count', '.sgpr_count',
                   '.vgpr_spill_count', '.sgpr_spill_count',
                   '.private_segment_fixed_size', '.group_segment_fixed_size')
@@ -297,7 +303,35 @@ class _Desc(ctypes.Structure):
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device', 'fused_waves_per_wg',
             'con_waves_per_wg', 'layout', 'inst_folded', 'fused_loses',
-            'jac_via_fused')]
+            'jac_via_fused', 'jac_persist', 'fused_persist')] + [
+        ('jac_class_cost', ctypes.c_float*32),
+        ('fused_class_cost', ctypes.c_float*32)]
+
+    def __init__(self, **kw):
+        for key in ('jac_class_cost', 'fused_class_cost'):
+            cost = list(kw.pop(key, ()))
+            setattr(self, key, (ctypes.c_float*32)(*cost[:32]))
+        super().__init__(**kw)
+
+
+def list_schedule(persist, node_blocks, class_cost):
+    """``opty_hip_list_schedule``: ``[[(class, block), ...] per workgroup]``
+    of a persistent kernel's launch over ``node_blocks`` 64-node blocks."""
+    import numpy as np
+    lib = load_library()
+    cost = (ctypes.c_float*len(class_cost))(*class_cost)
+    count = ctypes.c_int64()
+    _check(lib.opty_hip_list_schedule(persist, node_blocks, len(class_cost),
+                                      cost, None, 0, ctypes.byref(count)))
+    table = np.zeros(count.value, dtype=np.int32)
+    _check(lib.opty_hip_list_schedule(
+        persist, node_blocks, len(class_cost), cost,
+        table.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), len(table),
+        ctypes.byref(count)))
+    npw = int(table[0])
+    off, items = table[1:npw + 2], table[npw + 2:]
+    return [[(int(v) >> 24, (int(v) & 0xffffff)*8 + w % 8)
+             for v in items[off[w]:off[w + 1]]] for w in range(npw)]
 
 
 class _MatDesc(ctypes.Structure):
@@ -317,6 +351,10 @@ _lib = None
 #: every symbol ``include/opty_hip.h`` declares: (restype, argtypes)
 _P = ctypes.c_void_p
 _SIGNATURES = {
+    'opty_hip_list_schedule': (ctypes.c_int, [
+        ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+        ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
+        ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
     'opty_hip_create': (ctypes.c_int, [ctypes.POINTER(_Desc),
                                        ctypes.c_char_p,
                                        ctypes.POINTER(_P)]),

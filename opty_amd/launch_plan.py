@@ -315,7 +315,7 @@ def candidates(prog, node_blocks):
             shapes.append(('c16:', dict(chunk=16)))     # 17 KB less ring
         for pre, shape in shapes:
             base = dict(seed, **shape)
-            for order in ('class', 'tail'):
+            for order in ('class', 'tail', 'list'):
                 out.append(('jac:%s%s' % (pre, order),
                             dict(base, order=order)))
                 out.append(('fused:%s%s' % (pre, order),
@@ -332,6 +332,8 @@ def candidates(prog, node_blocks):
                     out.append(('fused:%s%s/%d' % (pre, tag, live), kw))
                     out.append(('fused:%s%s/%d:class' % (pre, tag, live),
                                 dict(kw, fused_order='class')))
+                    out.append(('fused:%s%s/%d:list' % (pre, tag, live),
+                                dict(kw, fused_order='list')))
                     break
     return out, g
 
@@ -360,7 +362,7 @@ def tune(collocator, iters=60, rounds=5, save=True, path=None, log=None,
         for attempt in (kw, dict(kw, con_split='count')):
             source, meta = emit_module(prog, EmitOptions(**attempt),
                                        node_blocks=blocks)
-            hsaco = hb.compile_module(source, col.tmp_dir)
+            hsaco = col._compile(source)
             spills = hb.vgpr_spills(hsaco)
             if 'opty_conjac' not in spills:
                 break

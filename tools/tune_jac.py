@@ -30,7 +30,8 @@ def parse(spec):
         k, v = item.split('=')
         kw[k] = None if v == 'None' else (
             v if k in ('ablate', 'con_split', 'small_flush', 'cut', 'order',
-                     'strips', 'fused_strips', 'fused_order')
+                     'strips', 'fused_strips', 'fused_order', 'class_cost',
+                     'fused_class_cost')
             else int(v))
     return EmitOptions(**kw)
 

@@ -71,16 +71,16 @@ def prebuild(names):
                 if meta['sha'] in seen:
                     continue
                 seen.add(meta['sha'])
-                def both(source=source, kw=kw, prog=prog, ln=ln):
+                def both(source=source, kw=kw, prog=prog, ln=ln, col=col):
                     # mirror launch_plan.tune: a candidate whose fused kernel
                     # spills vector registers is re-cut by count
-                    h = hb.compile_module(source)
+                    h = col._compile(source)
                     if 'opty_conjac' in hb.vgpr_spills(h) and \
                             'con_split' not in kw:
                         src2, _ = emit_module(
                             prog, EmitOptions(**dict(kw, con_split='count')),
                             node_blocks=(ln + 63)//64)
-                        h = hb.compile_module(src2)
+                        h = col._compile(src2)
                     return h
                 jobs.append((label, w, tag, pool.submit(both)))
         for label, w, tag, job in jobs:

@@ -96,6 +96,24 @@ def main():
                                         start[m].min(), np.median(start[m]),
                                         start[m].max(), end[m].max(),
                                         np.median(ghz)))
+        # what a SIMD does between two waves: the gap from one wave's end to
+        # the start of the next wave on the same SIMD
+        simd = hw & 0xf7f3f
+        gaps, busy, last = [], [], []
+        for k in np.unique(simd):
+            m = np.flatnonzero(simd == k)
+            m = m[np.argsort(start[m])]
+            gaps.extend(start[m][1:] - end[m][:-1])
+            busy.append((end[m] - start[m]).sum())
+            last.append(end[m].max())
+        gaps = np.array(gaps)
+        print('  per SIMD: busy med %.1f us of %.1f (%.0f %%), waves %.1f, gap '
+              'between waves med %.2f p90 %.2f max %.2f us (sum %.1f us per '
+              'SIMD), idle after the last wave med %.1f us'
+              % (np.median(busy), end.max(), 100*np.mean(busy)/end.max(),
+                 len(rec)/len(busy), np.median(gaps), np.percentile(gaps, 90),
+                 gaps.max(), gaps.sum()/len(busy),
+                 np.median(end.max() - np.array(last))), flush=True)
         ts = np.linspace(0, end.max(), 9)[1:-1]
         for t in ts:
             run = (start <= t) & (end > t)
