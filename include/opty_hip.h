@@ -144,6 +144,13 @@ typedef struct opty_hip_desc {
 #define OPTY_HIP_ABI_VERSION 6
 int opty_hip_abi_version(void);
 
+/* Build verification aid: leaves `pattern` in every vector / accumulation /
+ * free scalar register of every SIMD of the current device (and waits).  A
+ * referee that runs it before the kernel it checks sees a kernel that reads a
+ * register it never wrote -- the hipcc 7.2 faults of DESIGN.md 4.1 -- compute
+ * with the pattern instead of with the previous launch's values. */
+int opty_hip_poison_registers(unsigned pattern);
+
 /* The list schedule the library gives a persistent kernel (opty_hip_desc.
  * jac_persist / fused_persist) for a launch over `node_blocks` 64-node blocks
  * with `classes` strip classes of relative duration class_cost[g]: host

@@ -482,8 +482,10 @@ public:
         job_ = job;
         ready_.store(0, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
-        for (int c = 0; c < std::min(job.chunks, MAX_CHUNKS); ++c)
+        for (int c = 0; c < std::min(job.chunks, MAX_CHUNKS); ++c) {
             chunk_done_[c].store(0, std::memory_order_relaxed);
+            slice_next_[c].store(0, std::memory_order_relaxed);
+        }
         {
             std::lock_guard<std::mutex> lk(m_);
             ++epoch_;
@@ -574,8 +576,6 @@ private:
                 }
                 const long long a = j.nodes*c/j.chunks,
                                 b = j.nodes*(c + 1)/j.chunks;
-                const long long i0 = a + (b - a)*t/T,
-                                i1 = a + (b - a)*(t + 1)/T;
                 if (j.rows_dst) {
                     const long long c0 = j.bounds[c], c1 = j.bounds[c + 1];
                     const long long s0 = c0 + (c1 - c0)*t/T,
@@ -590,25 +590,39 @@ private:
                                                  std::memory_order_release);
                     continue;
                 }
-                if (j.seg_dst) {
-                    for (long long i = i0; i < i1; ++i) {
-                        const double *src = j.seg_src + i*j.L0;
-                        double *dst = j.seg_dst + i*j.L1;
-                        for (int k = 0; k < j.L1; ++k)
-                            dst[k] = src[j.seg_pos[k]];
+                // The nodes of a chunk in SLICES_PER_WORKER*T slices that the
+                // workers take from a counter, not one fixed share each: a
+                // worker that loses its core for a millisecond (other
+                // tenants of the host; the pinned workers cannot move) then
+                // holds back one slice, not a sixteenth of every chunk --
+                // scatter ends of 7-14 ms behind a 4.1 ms DMA were seen.
+                const int S = c < MAX_CHUNKS ? SLICES_PER_WORKER*T : T;
+                for (int k = c < MAX_CHUNKS ? slice_next_[c].fetch_add(
+                         1, std::memory_order_relaxed) : t; k < S;
+                     k = c < MAX_CHUNKS ? slice_next_[c].fetch_add(
+                         1, std::memory_order_relaxed) : S) {
+                    const long long s0 = a + (b - a)*k/S,
+                                    s1 = a + (b - a)*(k + 1)/S;
+                    if (j.seg_dst) {
+                        for (long long i = s0; i < s1; ++i) {
+                            const double *src = j.seg_src + i*j.L0;
+                            double *dst = j.seg_dst + i*j.L1;
+                            for (int q = 0; q < j.L1; ++q)
+                                dst[q] = src[j.seg_pos[q]];
+                        }
+                        continue;
                     }
-                    continue;
-                }
-                for (long long i = i0; i < i1; ++i) {
-                    const double *src = j.packed + i*j.V;
-                    double *dst = j.dense + i*j.P;
-                    for (int r = 0; r < j.nruns; ++r) {
-                        memcpy(dst + j.run_start[r], src,
-                               (size_t)j.run_len[r]*sizeof(double));
-                        src += j.run_len[r];
+                    for (long long i = s0; i < s1; ++i) {
+                        const double *src = j.packed + i*j.V;
+                        double *dst = j.dense + i*j.P;
+                        for (int r = 0; r < j.nruns; ++r) {
+                            memcpy(dst + j.run_start[r], src,
+                                   (size_t)j.run_len[r]*sizeof(double));
+                            src += j.run_len[r];
+                        }
+                        for (int q = 0; q < j.ncopies; ++q)
+                            dst[j.copy_dst[q]] = dst[j.copy_src[q]];
                     }
-                    for (int k = 0; k < j.ncopies; ++k)
-                        dst[j.copy_dst[k]] = dst[j.copy_src[k]];
                 }
             }
             done_.fetch_add(1, std::memory_order_release);
@@ -650,7 +664,9 @@ private:
 public:
     static constexpr int MAX_CHUNKS = 64;
 private:
+    static constexpr int SLICES_PER_WORKER = 4;
     std::atomic<int> chunk_done_[MAX_CHUNKS];
+    std::atomic<int> slice_next_[MAX_CHUNKS];
 };
 
 }  // namespace
@@ -1621,6 +1637,16 @@ void *opty_hip_host_alloc(size_t bytes) {
 
 int opty_hip_host_free(void *ptr) {
     if (ptr) HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
+#include "opty_poison.inc"
+
+int opty_hip_poison_registers(unsigned pattern) {
+    hipLaunchKernelGGL(opty_poison, dim3(4096), dim3(64), 0, nullptr, pattern,
+                       (unsigned *)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 

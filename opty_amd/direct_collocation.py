@@ -1172,9 +1172,18 @@ class ConstraintCollocator(object):
                 h.set_block_pattern(self._program.pattern)
             con = np.empty(self.num_eom*(N - 1))
             jac = np.empty(h.nnz)
+            # Before every kernel: NaNs into all register files.  The three
+            # kernels evaluate the same expressions of the same inputs one
+            # after the other, so a kernel that reads a register it never
+            # wrote (two of the frozen hipcc faults do) may find the RIGHT
+            # value there, left by its predecessor -- a box of r05 accepted
+            # tools/o3_repro/one_legged_park_spill_O2 that way.
+            hb.poison_registers()
             h.eval_con(free, con, hb.HOST)
+            hb.poison_registers()
             h.eval_jac(free, jac, hb.HOST)
             con2, jac2 = np.empty_like(con), np.empty_like(jac)
+            hb.poison_registers()
             h.eval_con_jac(free, con2, jac2, hb.HOST)
             return [con, jac, con2, jac2]
         finally:

@@ -73,7 +73,8 @@ def _hipcc():
 def build_runtime_library(force=False):
     """Compiles ``csrc/opty_hip.cpp`` into ``libopty_hip.so`` (in-tree)."""
     src = os.path.join(CSRC, 'opty_hip.cpp')
-    deps = [src, os.path.join(_PKG, '..', 'include', 'opty_hip.h')]
+    deps = [src, os.path.join(_PKG, '..', 'include', 'opty_hip.h'),
+            os.path.join(CSRC, 'opty_poison.inc')]
     if (not force and os.path.exists(LIB_PATH) and
             all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d)
                 for d in deps)):
@@ -314,6 +315,16 @@ class _Desc(ctypes.Structure):
         super().__init__(**kw)
 
 
+#: what the build referee leaves in the register files before every kernel
+#: it checks: a quiet NaN as either half of a double
+POISON = 0x7ff80000
+
+
+def poison_registers(pattern=POISON):
+    """``opty_hip_poison_registers`` on the current device."""
+    _check(load_library().opty_hip_poison_registers(pattern))
+
+
 def list_schedule(persist, node_blocks, class_cost):
     """``opty_hip_list_schedule``: ``[[(class, block), ...] per workgroup]``
     of a persistent kernel's launch over ``node_blocks`` 64-node blocks."""
@@ -351,6 +362,7 @@ _lib = None
 #: every symbol ``include/opty_hip.h`` declares: (restype, argtypes)
 _P = ctypes.c_void_p
 _SIGNATURES = {
+    'opty_hip_poison_registers': (ctypes.c_int, [ctypes.c_uint]),
     'opty_hip_list_schedule': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_int64, ctypes.c_int,
         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),

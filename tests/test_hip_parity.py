@@ -1225,11 +1225,33 @@ def test_spilling_parked_wave_is_refused():
     no vector spills -- is right (``tools/o3_repro/
     one_legged_park_spill_O2``).  The class every wrong build of round 3
     belonged to; the collocator never uses such a build (spill guard), the
-    referee refuses it as well."""
-    errors, _ = frozen_verdict('one_legged_park_spill_O2')
-    assert errors is not None, 'the referee accepted a build known wrong'
-    assert errors['opty_jac'] > 1e-2, errors
-    assert errors['opty_conjac'] < 1e-11 and errors['opty_con'] < 1e-11
+    referee refuses it as well -- whenever it IS wrong."""
+    from opty_amd import hip_backend as hb
+    errors, col = frozen_verdict('one_legged_park_spill_O2')
+    if errors is not None:
+        assert errors['opty_jac'] > 1e-2, errors
+        assert errors['opty_conjac'] < 1e-11 and errors['opty_con'] < 1e-11
+        return
+    # Whether the spilled registers come back intact depends on the box and
+    # on what ran before (the fault follows what registers and scratch held:
+    # profiles/r05_poison_probe.txt; two boxes of r05 returned right values
+    # from this very code object, with the referee's NaNs in every register
+    # file).  An acceptance must then be a RIGHT verdict: the frozen kernels'
+    # values are those of the collocator's own, verified build.
+    source, info = frozen_module('one_legged_park_spill_O2')
+    hsaco = hb.compile_module(source, col.tmp_dir,
+                              opt_level=info['opt_level'])
+    own_hsaco, own_meta = col._build_code_object()
+    col.hip
+    assert col._build_verdict['ok']
+    got = col._evaluate_build(info['meta'], hsaco)
+    want = col._evaluate_build(own_meta, own_hsaco)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g, w, rtol=1e-10,
+                                   atol=1e-10*np.abs(w).max())
+    import warnings
+    warnings.warn('one_legged_park_spill_O2 returned right values on this '
+                  'box: the referee accepted it, rightly')
 
 
 @pytest.mark.gpu
