@@ -479,12 +479,24 @@ public:
         // one job at a time: handles used from different host threads share
         // the pool (released by wait())
         busy_.lock();
+        quiesce();
         job_ = job;
+        open_ = true;
         ready_.store(0, std::memory_order_relaxed);
         done_.store(0, std::memory_order_relaxed);
+        // scatter jobs hand their nodes out in slices (see work())
+        slices_ = std::min(SLICES_PER_WORKER*threads(), MAX_SLICES);
+        static const bool fixed_shares =
+            getenv("OPTY_HIP_SCATTER_SHARES") != nullptr;   // A/B switch
+        sliced_ = !job.rows_dst && job.chunks <= MAX_CHUNKS && !fixed_shares;
+        slices_done_.store(0, std::memory_order_relaxed);
         for (int c = 0; c < std::min(job.chunks, MAX_CHUNKS); ++c) {
             chunk_done_[c].store(0, std::memory_order_relaxed);
             slice_next_[c].store(0, std::memory_order_relaxed);
+            if (sliced_)
+                for (int k = 0; k < slices_; ++k)
+                    slice_taken_[c*MAX_SLICES + k].store(
+                        0, std::memory_order_relaxed);
         }
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -493,10 +505,29 @@ public:
         cv_.notify_all();
     }
     void ready(int chunks) { ready_.store(chunks, std::memory_order_release); }
+    // A scatter job is over when every slice is in place -- whoever wrote it:
+    // a worker that lost its core in the middle of a slice (the hosts are
+    // shared: load averages of 40 were seen) is not waited for, the workers
+    // that are done repeat slices that have been in flight for too long.  It
+    // wakes up later and writes the same values once more; quiesce() keeps
+    // the next job (and the next DMA into the staging buffer it reads) behind
+    // it.
     void wait() {
-        while (done_.load(std::memory_order_acquire) < threads())
-            std::this_thread::yield();
+        if (sliced_) {
+            const int total = job_.chunks*slices_;
+            while (slices_done_.load(std::memory_order_acquire) < total)
+                std::this_thread::yield();
+        } else {
+            quiesce();
+        }
         busy_.unlock();
+    }
+    // every worker has left the last job
+    void quiesce() {
+        std::lock_guard<std::recursive_mutex> lk(busy_);
+        while (open_ && done_.load(std::memory_order_acquire) < threads())
+            std::this_thread::yield();
+        open_ = false;
     }
 
 private:
@@ -527,6 +558,39 @@ private:
         cv_.notify_all();
         for (auto &t : workers_) t.join();
         workers_.clear();
+        open_ = false;
+    }
+
+    static unsigned now_us() {
+        return (unsigned)std::chrono::duration_cast<std::chrono::microseconds>(
+            std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    // slice_taken_: 0 free, 1 done, else the time it was taken (odd)
+    void finish_slice(int c, int k) {
+        if (slice_taken_[c*MAX_SLICES + k].exchange(
+                1u, std::memory_order_acq_rel) != 1u)
+            slices_done_.fetch_add(1, std::memory_order_release);
+    }
+    static void scatter_nodes(const Job &j, long long s0, long long s1) {
+        if (j.seg_dst) {
+            for (long long i = s0; i < s1; ++i) {
+                const double *src = j.seg_src + i*j.L0;
+                double *dst = j.seg_dst + i*j.L1;
+                for (int q = 0; q < j.L1; ++q) dst[q] = src[j.seg_pos[q]];
+            }
+            return;
+        }
+        for (long long i = s0; i < s1; ++i) {
+            const double *src = j.packed + i*j.V;
+            double *dst = j.dense + i*j.P;
+            for (int r = 0; r < j.nruns; ++r) {
+                memcpy(dst + j.run_start[r], src,
+                       (size_t)j.run_len[r]*sizeof(double));
+                src += j.run_len[r];
+            }
+            for (int q = 0; q < j.ncopies; ++q)
+                dst[j.copy_dst[q]] = dst[j.copy_src[q]];
+        }
     }
 
     void work(int t, int T, unsigned long long seen) {
@@ -590,40 +654,58 @@ private:
                                                  std::memory_order_release);
                     continue;
                 }
-                // The nodes of a chunk in SLICES_PER_WORKER*T slices that the
-                // workers take from a counter, not one fixed share each: a
-                // worker that loses its core for a millisecond (other
-                // tenants of the host; the pinned workers cannot move) then
-                // holds back one slice, not a sixteenth of every chunk --
-                // scatter ends of 7-14 ms behind a 4.1 ms DMA were seen.
-                const int S = c < MAX_CHUNKS ? SLICES_PER_WORKER*T : T;
-                for (int k = c < MAX_CHUNKS ? slice_next_[c].fetch_add(
-                         1, std::memory_order_relaxed) : t; k < S;
-                     k = c < MAX_CHUNKS ? slice_next_[c].fetch_add(
-                         1, std::memory_order_relaxed) : S) {
-                    const long long s0 = a + (b - a)*k/S,
-                                    s1 = a + (b - a)*(k + 1)/S;
-                    if (j.seg_dst) {
-                        for (long long i = s0; i < s1; ++i) {
-                            const double *src = j.seg_src + i*j.L0;
-                            double *dst = j.seg_dst + i*j.L1;
-                            for (int q = 0; q < j.L1; ++q)
-                                dst[q] = src[j.seg_pos[q]];
+                if (!sliced_) {
+                    scatter_nodes(j, a + (b - a)*t/T, a + (b - a)*(t + 1)/T);
+                    continue;
+                }
+                // The nodes of a chunk in slices that the workers take from
+                // a counter, not one fixed share each: a worker that loses
+                // its core holds back one slice, not a sixteenth of every
+                // chunk.
+                const int S = slices_;
+                for (int k = slice_next_[c].fetch_add(
+                         1, std::memory_order_relaxed); k < S;
+                     k = slice_next_[c].fetch_add(
+                         1, std::memory_order_relaxed)) {
+                    slice_taken_[c*MAX_SLICES + k].store(
+                        std::max(2u, now_us()), std::memory_order_relaxed);
+                    scatter_nodes(j, a + (b - a)*k/S, a + (b - a)*(k + 1)/S);
+                    finish_slice(c, k);
+                }
+            }
+            // ... and slices that have been in flight for longer than a few
+            // of them take are written again by whoever is done (the same
+            // values from the same staging buffer)
+            while (sliced_) {
+                const int total = j.chunks*slices_;
+                if (slices_done_.load(std::memory_order_acquire) >= total)
+                    break;
+                bool helped = false;
+                const unsigned now = now_us();
+                for (int c = 0; c < j.chunks; ++c) {
+                    const long long a = j.nodes*c/j.chunks,
+                                    b = j.nodes*(c + 1)/j.chunks;
+                    for (int k = 0; k < slices_; ++k) {
+                        const unsigned at = slice_taken_[c*MAX_SLICES + k]
+                            .load(std::memory_order_relaxed);
+                        if (at == 0u) {
+                            // taken (the counter is past it) but not stamped
+                            // yet: its age counts from now
+                            unsigned zero = 0u;
+                            slice_taken_[c*MAX_SLICES + k]
+                                .compare_exchange_strong(
+                                    zero, std::max(2u, now),
+                                    std::memory_order_relaxed);
+                            continue;
                         }
-                        continue;
-                    }
-                    for (long long i = s0; i < s1; ++i) {
-                        const double *src = j.packed + i*j.V;
-                        double *dst = j.dense + i*j.P;
-                        for (int r = 0; r < j.nruns; ++r) {
-                            memcpy(dst + j.run_start[r], src,
-                                   (size_t)j.run_len[r]*sizeof(double));
-                            src += j.run_len[r];
-                        }
-                        for (int q = 0; q < j.ncopies; ++q)
-                            dst[j.copy_dst[q]] = dst[j.copy_src[q]];
+                        if (at == 1u || now - at < STALE_US) continue;
+                        scatter_nodes(j, a + (b - a)*k/slices_,
+                                      a + (b - a)*(k + 1)/slices_);
+                        finish_slice(c, k);
+                        helped = true;
                     }
                 }
+                if (!helped) cpu_relax();
             }
             done_.fetch_add(1, std::memory_order_release);
         }
@@ -664,9 +746,14 @@ private:
 public:
     static constexpr int MAX_CHUNKS = 64;
 private:
-    static constexpr int SLICES_PER_WORKER = 4;
+    static constexpr int SLICES_PER_WORKER = 4, MAX_SLICES = 256;
+    static constexpr unsigned STALE_US = 250;   // a slice takes 20-70 us
     std::atomic<int> chunk_done_[MAX_CHUNKS];
     std::atomic<int> slice_next_[MAX_CHUNKS];
+    std::atomic<unsigned> slice_taken_[MAX_CHUNKS*MAX_SLICES];
+    std::atomic<int> slices_done_{0};
+    int slices_ = 0;
+    bool sliced_ = false, open_ = false;
 };
 
 }  // namespace
@@ -2294,6 +2381,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     // chunks of about 16 MB: long enough for the DMA engine's full rate,
     // short enough that the host threads start early and finish soon after
     // the last byte has landed
+    ScatterPool::instance().quiesce();      // nobody reads h_packed any more
     int chunks = (int)std::max<size_t>(1, std::min<size_t>(
         32, packed*sizeof(double)/(16u << 20)));
     chunks = (int)std::min<long long>(chunks, count);
