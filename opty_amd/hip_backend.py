@@ -318,6 +318,8 @@ class _Desc(ctypes.Structure):
 #: what the build referee leaves in the register files before every kernel
 #: it checks: a quiet NaN as either half of a double
 POISON = 0x7ff80000
+#: ... once with each of these (ConstraintCollocator._verify_build)
+POISONS = (0x00000000, 0x7ff80000, 0xffffffff)
 
 
 def poison_registers(pattern=POISON):
@@ -526,6 +528,43 @@ def _ptr(x):
     if hasattr(x, 'data_ptr'):
         return x.data_ptr()
     return int(x)
+
+
+class DeviceVector(object):
+    """float64 device memory through the C ABI alone (``opty_hip_device_
+    alloc`` / ``opty_hip_memcpy``; no torch): what the build referee hands
+    the kernels, so that every output starts as NaN on the DEVICE -- a store
+    that never happens cannot hide behind what an earlier kernel left in a
+    buffer of the handle."""
+
+    def __init__(self, values, device=0):
+        self._lib = load_library()
+        host = np.ascontiguousarray(values, dtype=np.float64)
+        self.size = host.size
+        self.ptr = self._lib.opty_hip_device_alloc(device,
+                                                   max(8, host.nbytes))
+        if not self.ptr:
+            raise HipBackendError(self._lib.opty_hip_last_error().decode())
+        if host.size:
+            _check(self._lib.opty_hip_memcpy(self.ptr, host.ctypes.data,
+                                             host.nbytes, 0))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def numpy(self):
+        out = np.empty(self.size)
+        if self.size:
+            _check(self._lib.opty_hip_memcpy(out.ctypes.data, self.ptr,
+                                             out.nbytes, 1))
+        return out
+
+    def close(self):
+        if self.ptr:
+            self._lib.opty_hip_device_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
 
 
 class _PinnedBlock(object):

@@ -1141,9 +1141,10 @@ def prebuild_extras():
     import opty_amd
     from opty_amd import hip_backend as hb
     for tag in ('one_legged_csr_O1', 'biped_20_strips_O2',
-                'one_legged_park_spill_O2'):
+                'one_legged_park_spill_O2', 'biped_csr_persistent_O2'):
         source, info = frozen_module(tag)
-        hb.compile_module(source, opt_level=info['opt_level'])
+        hb.compile_module(source, opt_level=info['opt_level'],
+                          extra_flags=tuple(info.get('extra_flags', ())))
     for name in SPECIALISED:
         factory, fkw = problems.CONFIGS[name]
         opty_amd.ConstraintCollocator(specialize_parameters=True,
@@ -1169,7 +1170,8 @@ def frozen_verdict(tag, tmp_dir=None):
     col = opty_amd.ConstraintCollocator(**kw,
                                         **problems.build(info['problem']))
     hsaco = hb.compile_module(source, tmp_dir or col.tmp_dir,
-                              opt_level=info['opt_level'])
+                              opt_level=info['opt_level'],
+                              extra_flags=tuple(info.get('extra_flags', ())))
     res = hb.cached_kernel_resources(hsaco)
     for k, want in info['resources'].items():
         # the build the record describes (same compiler, same allocation)
@@ -1215,6 +1217,36 @@ def test_biped_build_with_twenty_strips_is_refused():
     assert errors is not None, 'the referee accepted a build known wrong'
     assert errors['opty_jac'] > 1e-3 and errors['opty_conjac'] > 1e-3
     assert errors['opty_con'] < 1e-11, errors
+
+
+@pytest.mark.gpu
+def test_persistent_biped_kernel_that_drops_stores_is_refused():
+    """Round 5's last find (``tools/list_soak.py``): the persistent build
+    (dispatch order 'list') of the biped in the row-sorted layout has a fused
+    kernel that drops the stores of 35 entries of one strip at every node (no
+    spilled vector registers, 290 spilled scalars: the class of
+    ``biped_20_strips_O2``).  The referee of the day ACCEPTED it: it
+    evaluated ``opty_jac`` and then ``opty_conjac`` through the same handle,
+    and what the fused kernel failed to store was still there, right, from
+    the kernel before.  It now gives every kernel device vectors of its own
+    that start as NaNs (and register files poisoned with each pattern of
+    ``hb.POISONS``)."""
+    from opty_amd import hip_backend as hb
+    errors, col = frozen_verdict('biped_csr_persistent_O2')
+    assert errors is not None, 'the referee accepted a build known wrong'
+    assert errors['opty_conjac'] > 1e-3, errors
+    assert errors['opty_con'] < 1e-11 and errors['opty_jac'] < 1e-11, errors
+    # what the pattern does (the reason for checking with several)
+    source, info = frozen_module('biped_csr_persistent_O2')
+    hsaco = hb.compile_module(source, col.tmp_dir,
+                              opt_level=info['opt_level'],
+                              extra_flags=tuple(info['extra_flags']))
+    lost = {}
+    for pattern in hb.POISONS:
+        jac2 = col._evaluate_build(info['meta'], hsaco, pattern=pattern)[3]
+        lost[hex(pattern)] = int(np.isnan(jac2).sum())
+    assert max(lost.values()) > 0, lost
+    print('stores that never happened, by register poison:', lost)
 
 
 @pytest.mark.gpu
