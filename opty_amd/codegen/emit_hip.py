@@ -109,6 +109,53 @@ KERNEL_PARAMS = (
     'long long node_end')
 
 
+_UNIFORM_TRIG_HELPERS = '''\
+// sincos behind a wave-uniform test (EmitOptions.fast_trig = 2): the short path
+// of opty_sincos (opty_device.h) when no lane of the wave needs the library's.
+__device__ __forceinline__ void optyu_sincos(double x, double *s, double *c) {
+    const bool odd = !(__builtin_fabs(x) <= 1048576.0);
+    if (__builtin_amdgcn_ballot_w64(odd) != 0ull) {
+        sincos(x, s, c);
+        return;
+    }
+    const double k = __builtin_rint(x*6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    r = __builtin_fma(-k, -1.49738490485916983294e-33, r);
+    const double z = r*r;
+    double ps = z*1.58969099521155010221e-10 + -2.50507602534068634195e-08;
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = __builtin_fma(z*r, ps, r);
+    double pc = z*-1.13596475577881948265e-11 + 2.08757232129817482790e-09;
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5*z;
+    const double w = 1.0 - hz;
+    const double cr = w + (((1.0 - w) - hz) + (z*z)*pc);
+    const int n = (int)k;
+    const bool swap = n & 1;
+    const double a = swap ? cr : sr;
+    const double b = swap ? sr : cr;
+    *s = (n & 2) ? -a : a;
+    *c = ((n + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ double optyu_sin(double x) {
+    double s, c;
+    optyu_sincos(x, &s, &c);
+    return s;
+}
+__device__ __forceinline__ double optyu_cos(double x) {
+    double s, c;
+    optyu_sincos(x, &s, &c);
+    return c;
+}'''
+
+
 _LOOP_HELPERS = '''\
 // Values the optimiser must take as new in every iteration of a persistent
 // kernel's item loops (see the kernels).
@@ -291,7 +338,14 @@ class EmitOptions(object):
         # r03_ab_fast_trig.txt): no gain -- 10-link fused 0.1362 vs 0.1357 ms,
         # 24-link 0.3848 vs 0.3841 ms, node shards the same -- the kernels
         # wait on LDS / scalar loads / the store queue, not on the vector
-        # ALU; kept as an option, off by default
+        # ALU; kept as an option, off by default.
+        # 2 (r05, experiment): the same kernels behind a WAVE-UNIFORM test --
+        # if any lane of the wave has a large (> 2^20), infinite or NaN
+        # argument, every lane takes the library's sincos, else every lane
+        # the short path: no if / else that narrows EXEC is left on the hot
+        # path of the generated kernels, which is where hipcc 7.2 misplaces
+        # register copies (profiles/r05_exec_fault.txt)
+        assert int(fast_trig) in (0, 1, 2)
         self.fast_trig = int(fast_trig)
         # non-temporal constraint stores: None = automatic (opty_con always;
         # opty_conjac when the constraint vector of a launch is too large to
@@ -344,7 +398,7 @@ class EmitOptions(object):
                 (' occupancy=%d' % self.occupancy if self.occupancy else '') +
                 (' con_nt=%d' % self.con_nt if self.con_nt is not None
                  else '') +
-                (' fast_trig=1' if self.fast_trig else '') +
+                (' fast_trig=%d' % self.fast_trig if self.fast_trig else '') +
                 (' fused_groups=%d' % self.fused_groups
                  if self.fused_groups is not None else '') +
                 ('' if self.small_flush == 'flat' else ' small_flush=chunk') +
@@ -399,7 +453,7 @@ class _Body(object):
     def __init__(self, dag, needed, leaf, fast_trig=True, deterministic=False):
         self.dag = dag
         self.deterministic = bool(deterministic)
-        self.trig = 'opty_' if fast_trig else ''
+        self.trig = {0: '', 1: 'opty_', 2: 'optyu_'}[int(fast_trig)]
         self.lines = []
         self.done = {}
         self.gen = 0
@@ -2536,6 +2590,8 @@ def emit_module(prog, opts=None, node_blocks=None, literals=None):
         head += [_PARK_HELPERS, '']
     if any(k.get('persist') for k in kernels.values()):
         head += [_LOOP_HELPERS, '']
+    if opts.fast_trig == 2:
+        head += [_UNIFORM_TRIG_HELPERS, '']
     source = '\n'.join(head + parts)
     meta = dict(kernels=kernels,
                 groups=[[list(rg) for rg in grp] for grp in groups],

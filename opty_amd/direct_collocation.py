@@ -841,8 +841,9 @@ class ConstraintCollocator(object):
         biped's default 20 strips are wrong in strip 17, identically in both
         Jacobian kernels, while 12, 24 and 32 strips, 16-entry chunks and the
         other ``sincos`` are right -- so the neighbouring geometries are
-        tried in the order of their expected cost (strips +2, +4, +1, +6 ...,
-        then ``fast_trig``, 16-entry chunks, then the same source through
+        tried in the order of their expected cost (r05: first the same
+        geometry with ``fast_trig=2``; strips +2, +4, +1, +6 ..., then
+        ``fast_trig=1``, 16-entry chunks, then the same source through
         ``-O1`` and without the pre-RA stage of round 3), several compiled at
         a time, each held to the instruction tape; the first accepted one is
         used, remembered by this collocator and recorded in the plan file as
@@ -858,6 +859,12 @@ class ConstraintCollocator(object):
         # (an explicit strip count is an even cut unless the work-aware one
         # is asked for: the neighbours of a work-aware cut are work-aware)
         keep = dict(cut='work') if geo.get('cut') == 'work' else {}
+        if base.fast_trig != 2:
+            # first the SAME geometry with sincos behind a wave-uniform test:
+            # the one fault that is understood (profiles/r05_exec_fault.txt)
+            # sits in the if / else of the inlined library sincos, and the
+            # plan's measured geometry stays
+            cands.append(('uniform_trig', dict(fast_trig=2), {}))
         if geo['line_mode'] or self._jacobian_layout == 'csr':
             for d in (2, 4, 1, 6, 8, 12, -2, -4):
                 if min(geo['jac'], geo['fused']) + d >= 1:

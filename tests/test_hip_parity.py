@@ -1250,6 +1250,46 @@ def test_persistent_biped_kernel_that_drops_stores_is_refused():
 
 
 @pytest.mark.gpu
+def test_refused_persistent_build_is_replaced_by_the_uniform_sincos_one(
+        tmp_path, monkeypatch):
+    """The same problem through the collocator: a plan that asks for the
+    persistent kernels hipcc gets wrong (above) is refused by the referee and
+    replaced by the SAME geometry with ``sincos`` behind a wave-uniform test
+    (``fast_trig=2``: no if / else that narrows EXEC on the kernels' hot
+    path, which is where the misplaced register copy sits --
+    ``profiles/r05_exec_fault.txt``); values as the default build's."""
+    import json
+    import opty_amd
+    from opty_amd import launch_plan as lp
+    kw = problems.build('biped_mid_small')
+    ref = opty_amd.ConstraintCollocator(jacobian_layout='csr', **kw)
+    free = problems.make_free(ref.num_free, seed=11)
+    con0 = ref.generate_constraint_function()(free)
+    jac0 = np.array(ref.generate_jacobian_function()(free))
+    key = lp.key_of(ref._build_program(), ref._launch_blocks())
+    path = tmp_path/'plans.json'
+    monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(path))
+    path.write_text(json.dumps({key: dict(options=dict(
+        order='list', fused_order='list'))}))
+    col = opty_amd.ConstraintCollocator(jacobian_layout='csr',
+                                        tmp_dir=str(tmp_path/'cache'), **kw)
+    hip = col.hip
+    verdict = col._build_verdict
+    assert verdict['ok'] and verdict.get('replacement') == 'uniform_trig', \
+        verdict
+    assert hip.desc['fused_persist'] == 1024
+    assert col._built_options.fast_trig == 2
+    con, jac = np.empty_like(con0), np.empty_like(jac0)
+    hip.eval_con_jac(free, con, jac, opty_amd.hip_backend.HOST)
+    np.testing.assert_allclose(jac, jac0, rtol=1e-12,
+                               atol=1e-12*np.abs(jac0).max())
+    np.testing.assert_allclose(con, con0, rtol=1e-12,
+                               atol=1e-12*np.abs(con0).max())
+    np.testing.assert_allclose(np.array(col.generate_jacobian_function()(
+        free)), jac0, rtol=1e-12, atol=1e-12*np.abs(jac0).max())
+
+
+@pytest.mark.gpu
 def test_spilling_parked_wave_is_refused():
     """Round 5's find: a planned wave with LDS parking whose Jacobian-only
     kernel spills 72 vector registers at ``-O2`` returns garbage (7.8 x the
