@@ -43,10 +43,21 @@ def main():
         # kernels (ConstraintCollocator(specialize_parameters=True))
         special = 'specialize' in spec
         determ = '+deterministic' in spec
+        uniform = '+uniform_trig' in spec
         bare = spec.replace('+specialize', '').replace(',specialize=1', '') \
-            .replace('specialize=1', '').replace('+deterministic', '')
+            .replace('specialize=1', '').replace('+deterministic', '') \
+            .replace('+uniform_trig', '')
         opts = None if bare in ('auto', '') else (
             EmitOptions() if bare == 'default' else parse(bare))
+        if uniform:
+            # the plan's (or the given) options with sincos behind a
+            # wave-uniform test (EmitOptions.fast_trig = 2)
+            import copy
+            if opts is None:
+                opts = opty_amd.ConstraintCollocator(
+                    specialize_parameters=special, **kw)._printer_options()
+            opts = copy.copy(opts)
+            opts.fast_trig = 2
         col = opty_amd.ConstraintCollocator(
             emit_options=opts, specialize_parameters=special,
             deterministic=determ, **kw)
