@@ -7,7 +7,8 @@ fused evaluation, tape-refereed builds.
 
     python tools/list_soak.py --prebuild [i n]   # CPU: compile (share i of n)
     python tools/list_soak.py [substring ...]    # GPU box: compare
-env: LIST_SOAK_SKIP = comma-separated substrings of names to leave out
+env: SOAK_OPTIONS = printer options to force (default order=list,fused_order=list)
+     LIST_SOAK_SKIP = comma-separated substrings of names to leave out
      (default: the 24-link stand-ins, whose modules take minutes to compile)
 """
 import copy
@@ -38,7 +39,12 @@ def siblings(shard=None, only=()):
         if only and not any(a in label for a in only):
             continue
         opts = copy.copy(col._printer_options())
-        opts.order = opts.fused_order = 'list'
+        # SOAK_OPTIONS="fast_trig=2": other printer options than the
+        # persistent kernels' (e.g. the uniform-sincos replacement build)
+        forced = os.environ.get('SOAK_OPTIONS', 'order=list,fused_order=list')
+        for item in forced.split(','):
+            k, v = item.split('=')
+            setattr(opts, k, int(v) if v.lstrip('-').isdigit() else v)
         yield label, col, opty_amd.ConstraintCollocator(
             emit_options=opts, **kw, **pkw)
 
