@@ -495,7 +495,7 @@ public:
             slice_next_[c].store(0, std::memory_order_relaxed);
             if (sliced_)
                 for (int k = 0; k < slices_; ++k)
-                    slice_taken_[c*MAX_SLICES + k].store(
+                    slice_state_[c*MAX_SLICES + k].v.store(
                         0, std::memory_order_relaxed);
         }
         {
@@ -565,9 +565,9 @@ private:
         return (unsigned)std::chrono::duration_cast<std::chrono::microseconds>(
             std::chrono::steady_clock::now().time_since_epoch()).count();
     }
-    // slice_taken_: 0 free, 1 done, else the time it was taken (odd)
+    // slice_state_[].v: 0 free, 1 done, else the time it was taken (odd)
     void finish_slice(int c, int k) {
-        if (slice_taken_[c*MAX_SLICES + k].exchange(
+        if (slice_state_[c*MAX_SLICES + k].v.exchange(
                 1u, std::memory_order_acq_rel) != 1u)
             slices_done_.fetch_add(1, std::memory_order_release);
     }
@@ -667,7 +667,7 @@ private:
                          1, std::memory_order_relaxed); k < S;
                      k = slice_next_[c].fetch_add(
                          1, std::memory_order_relaxed)) {
-                    slice_taken_[c*MAX_SLICES + k].store(
+                    slice_state_[c*MAX_SLICES + k].v.store(
                         std::max(2u, now_us()), std::memory_order_relaxed);
                     scatter_nodes(j, a + (b - a)*k/S, a + (b - a)*(k + 1)/S);
                     finish_slice(c, k);
@@ -686,13 +686,13 @@ private:
                     const long long a = j.nodes*c/j.chunks,
                                     b = j.nodes*(c + 1)/j.chunks;
                     for (int k = 0; k < slices_; ++k) {
-                        const unsigned at = slice_taken_[c*MAX_SLICES + k]
+                        const unsigned at = slice_state_[c*MAX_SLICES + k].v
                             .load(std::memory_order_relaxed);
                         if (at == 0u) {
                             // taken (the counter is past it) but not stamped
                             // yet: its age counts from now
                             unsigned zero = 0u;
-                            slice_taken_[c*MAX_SLICES + k]
+                            slice_state_[c*MAX_SLICES + k].v
                                 .compare_exchange_strong(
                                     zero, std::max(2u, now),
                                     std::memory_order_relaxed);
@@ -705,7 +705,13 @@ private:
                         helped = true;
                     }
                 }
-                if (!helped) cpu_relax();
+                // (look again in a while: the scan reads every stamp, and
+                // the workers still at it are writing theirs)
+                if (!helped)
+                    for (int spin = 0; spin < 256 &&
+                         slices_done_.load(std::memory_order_acquire) < total;
+                         ++spin)
+                        cpu_relax();
             }
             done_.fetch_add(1, std::memory_order_release);
         }
@@ -750,7 +756,9 @@ private:
     static constexpr unsigned STALE_US = 250;   // a slice takes 20-70 us
     std::atomic<int> chunk_done_[MAX_CHUNKS];
     std::atomic<int> slice_next_[MAX_CHUNKS];
-    std::atomic<unsigned> slice_taken_[MAX_CHUNKS*MAX_SLICES];
+    // (a cache line each: sixteen workers stamp their slices all the time)
+    struct alignas(64) SliceState { std::atomic<unsigned> v{0}; };
+    SliceState slice_state_[MAX_CHUNKS*MAX_SLICES];
     std::atomic<int> slices_done_{0};
     int slices_ = 0;
     bool sliced_ = false, open_ = false;

@@ -22,7 +22,9 @@ from examples import problems                                 # noqa: E402
 def main():
     calls = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     kw = problems.build('config3_10link')
-    a = opty_amd.ConstraintCollocator(**kw)
+    # HOST_CALLS_PRUNE=1: the pruned block (structural zeros dropped) instead
+    a = opty_amd.ConstraintCollocator(
+        prune_zeros=os.environ.get('HOST_CALLS_PRUNE') == '1', **kw)
     b = opty_amd.ConstraintCollocator(jacobian_layout='varying_first', **kw)
     ja, jb = a.generate_jacobian_function(), b.generate_jacobian_function()
     frees = [problems.make_free(a.num_free, seed=s) for s in range(3)]
