@@ -398,7 +398,7 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
     torch.cuda.empty_cache()
 
 
-def host_path(kw, dev_index, reps=7):
+def host_path(kw, dev_index, reps=15):
     """Wall time of the host (cyipopt-callback) path of config 3: NumPy in,
     NumPy out through ``generate_*_function`` (PCIe inclusive): the
     reference's dense-block contract as the callbacks serve it (``jac``:
@@ -419,8 +419,13 @@ def host_path(kw, dev_index, reps=7):
             t0 = time.perf_counter()
             fn(frees[k % len(frees)])
             ts.append(time.perf_counter() - t0)
+        # (the hosts are shared: the median of 15 calls -- 70 ms -- rides out
+        # a burst of somebody else's load that the median of 7 did not; the
+        # fastest call is recorded next to it)
+        best[0] = 1e3*min(ts)
         return 1e3*sorted(ts)[len(ts)//2]
 
+    best = [0.0]
     out = {}
     for label, extra in (('', {}), ('_pruned', {'prune_zeros': True}),
                          ('_varying_first',
@@ -444,7 +449,8 @@ def host_path(kw, dev_index, reps=7):
         # over its first calls -- opty_hip.cpp ScatterPool::feedback; they are
         # warm-up)
         jf = col.generate_jacobian_function()
-        out['jac' + label] = med(jf, frees, warm=14 if not label else 2)
+        out['jac' + label] = med(jf, frees, warm=14 if not label else 4)
+        out['jac' + label + '_min'] = best[0]
         if not label:
             # where the bytes and the threads are (so that a slow line can be
             # read): NUMA node of the persistent vector, of the scatter
