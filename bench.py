@@ -445,11 +445,11 @@ def host_path(kw, dev_index, reps=15):
             # ... of which only the distinct expressions cross PCIe
             out['moved_entries_per_block'] = len(unique)
             out['host_threads'] = hb.host_threads()
-        # (the default layout's host scatter verifies its thread placement
-        # over its first calls -- opty_hip.cpp ScatterPool::feedback; they are
-        # warm-up)
+        # (the host scatter verifies its thread placement over the first
+        # calls with every new vector -- opty_hip.cpp ScatterPool::feedback;
+        # they are warm-up, for each of the three collocators)
         jf = col.generate_jacobian_function()
-        out['jac' + label] = med(jf, frees, warm=14 if not label else 4)
+        out['jac' + label] = med(jf, frees, warm=14)
         out['jac' + label + '_min'] = best[0]
         if not label:
             # where the bytes and the threads are (so that a slow line can be
