@@ -486,9 +486,11 @@ public:
         done_.store(0, std::memory_order_relaxed);
         // scatter jobs hand their nodes out in slices (see work())
         slices_ = std::min(SLICES_PER_WORKER*threads(), MAX_SLICES);
-        static const bool fixed_shares =
-            getenv("OPTY_HIP_SCATTER_SHARES") != nullptr;   // A/B switch
-        sliced_ = !job.rows_dst && job.chunks <= MAX_CHUNKS && !fixed_shares;
+        // opt-in (OPTY_HIP_SCATTER_SLICES=1): on the hosts this could be
+        // measured on it bought nothing and cost the pruned layout 0.5-1 ms
+        // (DESIGN.md 5.2); the default is one fixed share per worker
+        static const bool slices = getenv("OPTY_HIP_SCATTER_SLICES") != nullptr;
+        sliced_ = !job.rows_dst && job.chunks <= MAX_CHUNKS && slices;
         slices_done_.store(0, std::memory_order_relaxed);
         for (int c = 0; c < std::min(job.chunks, MAX_CHUNKS); ++c) {
             chunk_done_[c].store(0, std::memory_order_relaxed);

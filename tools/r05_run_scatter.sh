@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
 cat /proc/loadavg
-for P in 0 1; do
-  echo "== prune_zeros=$P slices"; HOST_CALLS_PRUNE=$P python tools/host_path_calls.py 40 2>&1 | tail -2 | head -1
-  echo "== prune_zeros=$P fixed shares"; HOST_CALLS_PRUNE=$P OPTY_HIP_SCATTER_SHARES=1 python tools/host_path_calls.py 40 2>&1 | tail -2 | head -1
-  echo "== prune_zeros=$P slices"; HOST_CALLS_PRUNE=$P python tools/host_path_calls.py 40 2>&1 | tail -2 | head -1
-  echo "== prune_zeros=$P fixed shares"; HOST_CALLS_PRUNE=$P OPTY_HIP_SCATTER_SHARES=1 python tools/host_path_calls.py 40 2>&1 | tail -2 | head -1
+for i in 1 2 3; do
+  python tools/bench_host_path_only.py 2>/dev/null | tail -1 | cut -c1-330
+  OPTY_HIP_SCATTER_SLICES=1 python tools/bench_host_path_only.py 2>/dev/null | tail -1 | cut -c1-330
 done
