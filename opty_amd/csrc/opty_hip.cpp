@@ -719,6 +719,9 @@ private:
         }
     }
 
+public:
+    static inline void pause() { cpu_relax(); }
+private:
     static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
@@ -2468,7 +2471,20 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     int rc = 0;
     double t_first = 0.0;
     for (int c = 0; c < chunks; ++c) {
-        hipError_t e = hipEventSynchronize(p->chunk_events[c]);
+        // OPTY_HIP_EVENT_WAIT=poll: query in a loop instead of the runtime's
+        // wait (experiment: slow modes of this pipeline on shared hosts)
+        static const bool poll = [] {
+            const char *v = getenv("OPTY_HIP_EVENT_WAIT");
+            return v && strcmp(v, "poll") == 0;
+        }();
+        hipError_t e;
+        if (poll) {
+            while ((e = hipEventQuery(p->chunk_events[c])) ==
+                   hipErrorNotReady)
+                ScatterPool::pause();
+        } else {
+            e = hipEventSynchronize(p->chunk_events[c]);
+        }
         if (e != hipSuccess && rc == 0) {
             (void)hipGetLastError();
             rc = fail("hipEventSynchronize failed: %s", hipGetErrorString(e));
