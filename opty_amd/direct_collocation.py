@@ -939,13 +939,19 @@ class ConstraintCollocator(object):
         meta)``."""
         return self._build_code_object()
 
-    #: nodes the automatic check below evaluates (``OPTY_CROSS_CHECK=off``
-    #: disables it, ``=hot`` restricts it to builds at the register limit)
+    #: nodes the automatic check below evaluates (``verify_builds='off'``
+    #: disables it; ``OPTY_CROSS_CHECK=hot`` -- or ``=off`` -- in the
+    #: environment restricts it to builds at the register limit)
     _VERIFY_NODES = 199
     _VERIFY_RTOL = 1e-9
     #: disagreements up to this are re-examined on a second set of inputs
     #: (an ill-conditioned row), larger ones refuse the build at once
     _VERIFY_CONFIRM = 1e-6
+    #: version of the referee a cached verdict must come from: 1 = host
+    #: arrays (r04), 2 = register poison + device vectors of its own (r05),
+    #: 3 = marginal disagreements settled by the entries' own rounding-error
+    #: bounds on two seeds, not by the better of two seeds (r06)
+    _REFEREE_VERSION = 3
 
     def _verify_build(self, hsaco, meta, force=False):
         """Holds a build to the expression DAG itself before the handle is
@@ -955,7 +961,9 @@ class ConstraintCollocator(object):
         the code object); ``OPTY_CROSS_CHECK=hot`` restricts it to the builds
         that have actually failed -- kernels at the edge of the register file
         (``hip_backend.high_pressure_kernels``: >= 480 VGPRs or spilled
-        SGPRs) --, ``=off`` disables it.
+        SGPRs); ``=off`` in the environment means the same (those builds
+        cannot be exempted from outside), only ``verify_builds='off'`` given
+        to the constructor disables the check.
 
         Why: hipcc 7.2 has produced code objects of exactly such kernels
         whose values are wrong, deterministically and in whole strips:
@@ -978,8 +986,16 @@ class ConstraintCollocator(object):
         remembered next to the code object (``<hsaco>.crosscheck.json``)."""
         import json
         import os
-        mode = (self._verify_mode or
-                os.environ.get('OPTY_CROSS_CHECK', '')).lower()
+        mode = self._verify_mode
+        if mode is None:
+            # the environment may restrict the check to the class that has
+            # failed (kernels at the register limit), it cannot switch it
+            # off for that class: ``off`` there reads as ``hot``.  Opting
+            # out altogether is an API decision (``verify_builds='off'``),
+            # made where the collocator is made (VERDICT r05 item 4d)
+            mode = os.environ.get('OPTY_CROSS_CHECK', '').lower()
+            if mode == 'off':
+                mode = 'hot'
         if mode == 'off':
             return None
         if hb.load_library().opty_hip_device_count() <= 0:
@@ -991,7 +1007,12 @@ class ConstraintCollocator(object):
         try:
             with open(side) as f:
                 verdict = json.load(f)
-            if verdict.get('ok') is True and verdict.get('referee') == 'tape':
+            # (verdicts of an older referee are not trusted: the one without
+            # register poison and device vectors of its own ACCEPTED two
+            # faulty builds in r05)
+            if verdict.get('ok') is True and verdict.get('referee') == 'tape' \
+                    and verdict.get('referee_version') == \
+                    self._REFEREE_VERSION:
                 return verdict
         except (OSError, ValueError):
             pass
@@ -1005,9 +1026,10 @@ class ConstraintCollocator(object):
             rcon, rjac, con_row, jac_row = self._reference_values(span=span)
             if np.isfinite(rcon).all() and np.isfinite(rjac).all():
                 break
-        def compare(seed):
+        def compare(seed, floors=(None, None)):
             rcon, rjac, con_row, jac_row = self._reference_values(
                 seed=seed, span=span)
+            fcon, fjac = floors
             worst = {}
             # once per register poison (see _evaluate_build): a kernel that
             # reads a register it never wrote may come out right with ONE
@@ -1017,31 +1039,48 @@ class ConstraintCollocator(object):
                 con, jac, con2, jac2 = self._evaluate_build(
                     meta, hsaco, seed=seed, span=span, pattern=pattern)
                 got = {
-                    'opty_con': self._row_error(con, rcon, con_row),
-                    'opty_jac': self._row_error(jac, rjac, jac_row),
+                    'opty_con': self._row_error(con, rcon, con_row, fcon),
+                    'opty_jac': self._row_error(jac, rjac, jac_row, fjac),
                     'opty_conjac': max(
-                        self._row_error(con2, rcon, con_row),
-                        self._row_error(jac2, rjac, jac_row))}
+                        self._row_error(con2, rcon, con_row, fcon),
+                        self._row_error(jac2, rjac, jac_row, fjac))}
                 worst = {k: max(v, worst.get(k, 0.0))
                          for k, v in got.items()}
             return worst
 
         errors = compare(7)
         worst = max(errors.values())
+        marginal = None
         if self._VERIFY_RTOL < worst <= self._VERIFY_CONFIRM:
-            # A small disagreement may be an ill-conditioned row (a
-            # cancellation, 1/x next to a pole) whose contraction into FMAs
-            # differs between the kernel and the one-operation-per-
-            # instruction tape, not a wrong build: every wrong build seen so
-            # far was wrong at EVERY node by >= 1e-3 of its row.  Such a
-            # verdict is confirmed on other inputs before a build is refused.
-            again = compare(8)
-            logger.info('marginal disagreement %s confirmed on a second '
-                        'seed: %s', errors, again)
-            errors = {k: min(errors[k], again[k]) for k in errors}
+            # A small disagreement may be an ill-conditioned entry (a
+            # cancellation, 1/x next to a pole) that the kernel's FMA
+            # contraction and operation order round differently from the
+            # one-operation-per-instruction tape -- or a small compiler
+            # fault.  The two are told apart by the entry's OWN rounding-
+            # error bound (codegen/errbound.py: a running error analysis of
+            # the DAG at the verification inputs), not by looking for a
+            # seed on which the number is smaller: on both
+            # seeds every entry must sit within _VERIFY_RTOL of its row
+            # once _VERIFY_BOUND_UNITS of its own bound are taken off, and
+            # the LARGER of the two errors counts.  A build that is off by
+            # 1e-7 of a well-conditioned row fails this however small 1e-7
+            # looks.
+            beyond = {}
+            for seed in (7, 8):
+                got = compare(seed, self._rounding_floors(seed, span))
+                beyond = {k: max(v, beyond.get(k, 0.0))
+                          for k, v in got.items()}
+            marginal = dict(raw=dict(errors), beyond_rounding_bound=beyond,
+                            bound_units=self._VERIFY_BOUND_UNITS)
+            logger.info('marginal disagreement %s; beyond the entries\' own '
+                        'rounding-error bounds on two seeds: %s', errors,
+                        beyond)
+            errors = beyond
             worst = max(errors.values())
         verdict = dict(ok=bool(worst <= self._VERIFY_RTOL), referee='tape',
-                       worst=worst, errors=errors, span=list(span),
+                       referee_version=self._REFEREE_VERSION,
+                       worst=max(errors.values()), errors=errors,
+                       marginal=marginal, span=list(span),
                        nodes=int(
                            min(self.num_collocation_nodes,
                                self._VERIFY_NODES)),
@@ -1066,17 +1105,21 @@ class ConstraintCollocator(object):
     _VERIFY_SPANS = ((-1.0, 1.0), (0.1, 0.9), (0.45, 0.55))
 
     @staticmethod
-    def _row_error(got, want, row):
+    def _row_error(got, want, row, floor=None):
         """Largest difference between two vectors relative to the largest
         (finite) reference value of the entry's own equation; ``row[k]`` =
         equation of entry ``k``.  Entries that are NaN in both, or the same
-        infinity in both, agree; any other non-finite difference is inf."""
+        infinity in both, agree; any other non-finite difference is inf.
+        ``floor`` (array like ``want``): what an entry may differ by for
+        reasons of its own conditioning -- only the excess counts."""
         if not want.size:
             return 0.0
         with np.errstate(all='ignore'):
             same = (np.isnan(got) & np.isnan(want)) | (
                 np.isinf(got) & np.isinf(want) & (got == want))
             d = np.where(same, 0.0, np.abs(got - want))
+            if floor is not None:
+                d = np.where(d <= floor, 0.0, d)
         if not np.isfinite(d).all():
             return float('inf')
         scale = np.zeros(int(row.max()) + 1)
@@ -1108,18 +1151,10 @@ class ConstraintCollocator(object):
             if self.num_known_input_trajectories else None
         return self._tape_values(free, N, 0, N - 1, known)
 
-    def _tape_values(self, free, N, a, b, known):
-        """Constraints and Jacobian values of the constraint nodes ``[a, b)``
-        of an ``N``-node problem with free vector ``free`` (known
-        trajectories ``known``, ``(m_known, N)``), evaluated from the
-        expression DAG by the instruction tape on the device
-        (``opty_hip_tape_run``): ``(con, jac, con_row, jac_row)`` in the
-        layouts the kernels write for that node range -- ``con[j*(b-a) +
-        i]``; ``jac[i*P + e]``, or ``jac[S_j*(b-a) + i*L_j + pos]`` for the
-        row-sorted layout -- with ``*_row[k]`` = equation of entry ``k``."""
-        from .codegen.tape import Tape
+    def _node_inputs(self, free, N, a, b, known):
+        """``inputs(kind, index)`` of the constraint nodes ``[a, b)`` of an
+        ``N``-node problem: what a DAG INPUT node reads there."""
         prog = self._build_program()
-        ncn = b - a
         n, q = prog.n, prog.q
         tail = free[(n + q)*N:]
         kpar = [float(self.known_parameter_map[p])
@@ -1137,17 +1172,21 @@ class ConstraintCollocator(object):
             assert kind == 'h', kind
             return self.node_time_interval if prog.h[0] == 'fixed' \
                 else tail[prog.h[1]]
+        return inputs
 
-        if self._tape is None:
-            self._tape = Tape(prog.dag,
-                              list(prog.con_out) + list(prog.jac_out))
-        tape = self._tape
-        vals = hb.tape_run(tape, tape.table(ncn, inputs), self._device)
+    def _kernel_layout(self, con_vals, jac_vals, ncn):
+        """Per-root vectors of ``ncn`` nodes (``con_vals[j]``, ``jac_vals[e]``)
+        in the layouts the kernels write for a node range: ``(con, jac,
+        con_row, jac_row)`` with ``con[j*ncn + i]``; ``jac[i*P + e]``, or
+        ``jac[S_j*ncn + i*L_j + pos]`` for the row-sorted layout;
+        ``*_row[k]`` = equation of entry ``k``."""
+        prog = self._build_program()
         M, P = prog.M, prog.P
-        con = np.concatenate([vals[tape.slot[r]] for r in prog.con_out]) \
+        ones = np.ones(ncn)
+        con = np.concatenate([np.atleast_1d(v)*ones for v in con_vals]) \
             if M else np.zeros(0)
         con_row = np.repeat(np.arange(M), ncn)
-        block = np.stack([vals[tape.slot[r]] for r in prog.jac_out], axis=1) \
+        block = np.stack([np.atleast_1d(v)*ones for v in jac_vals], axis=1) \
             if P else np.zeros((ncn, 0))                # (ncn, P)
         ent_row = np.array([j for j, _ in prog.pattern], dtype=np.int64)
         if self._jacobian_layout == 'csr':
@@ -1163,6 +1202,52 @@ class ConstraintCollocator(object):
             jac = block.ravel()
             jac_row = np.tile(ent_row, ncn)
         return con, jac, con_row, jac_row
+
+    def _tape_values(self, free, N, a, b, known):
+        """Constraints and Jacobian values of the constraint nodes ``[a, b)``
+        of an ``N``-node problem with free vector ``free`` (known
+        trajectories ``known``, ``(m_known, N)``), evaluated from the
+        expression DAG by the instruction tape on the device
+        (``opty_hip_tape_run``): ``(con, jac, con_row, jac_row)`` in the
+        layouts the kernels write for that node range
+        (:meth:`_kernel_layout`)."""
+        from .codegen.tape import Tape
+        prog = self._build_program()
+        ncn = b - a
+        inputs = self._node_inputs(free, N, a, b, known)
+        if self._tape is None:
+            self._tape = Tape(prog.dag,
+                              list(prog.con_out) + list(prog.jac_out))
+        tape = self._tape
+        vals = hb.tape_run(tape, tape.table(ncn, inputs), self._device)
+        return self._kernel_layout([vals[tape.slot[r]] for r in prog.con_out],
+                                   [vals[tape.slot[r]] for r in prog.jac_out],
+                                   ncn)
+
+    #: what a kernel may differ from the tape by beyond ``_VERIFY_RTOL`` of
+    #: its row: this many units of the entry's own first-order rounding-error
+    #: bound (``codegen/errbound.py``; the parity tests' floor is 32 units)
+    _VERIFY_BOUND_UNITS = 64.0
+
+    def _rounding_floors(self, seed=7, span=(-1.0, 1.0)):
+        """``(con_floor, jac_floor)`` in the kernels' layouts: per entry,
+        ``_VERIFY_BOUND_UNITS`` x unit round-off x the running error bound of
+        the entry's own operations at the verification inputs."""
+        from .codegen.errbound import evaluate_with_error_bound
+        prog = self._build_program()
+        N, free = self._verification_inputs(seed, span)
+        known = self._known_trajectory_array(np.ones(self.num_free))[:, :N] \
+            if self.num_known_input_trajectories else None
+        inputs = self._node_inputs(free, N, 0, N - 1, known)
+        _, ce = evaluate_with_error_bound(prog.dag, list(prog.con_out),
+                                          inputs)
+        _, je = evaluate_with_error_bound(prog.dag, list(prog.jac_out),
+                                          inputs)
+        con, jac, _, _ = self._kernel_layout(ce, je, N - 1)
+        unit = self._VERIFY_BOUND_UNITS*2.0**-53
+        with np.errstate(all='ignore'):
+            return (np.nan_to_num(con*unit, nan=0.0, posinf=0.0),
+                    np.nan_to_num(jac*unit, nan=0.0, posinf=0.0))
 
     def _evaluate_build(self, meta, hsaco, seed=7, span=(-1.0, 1.0),
                         pattern=None):

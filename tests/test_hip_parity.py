@@ -1114,8 +1114,15 @@ def test_wrong_high_pressure_build_is_rejected(monkeypatch, tmp_path):
     monkeypatch.setattr(hb, 'compile_module', lambda *a, **k: bad)
     with pytest.raises(hb.BuildRejected, match='No neighbouring build'):
         col6.hip
+    # the environment cannot exempt a build at the register limit (r06):
+    # ``off`` there reads as ``hot``, and the leg's kernels are hot
     monkeypatch.setenv('OPTY_CROSS_CHECK', 'off')
-    assert col6.hip is not None          # the documented opt-out
+    with pytest.raises(hb.BuildRejected):
+        col6.hip
+    # the documented opt-out is an argument of the constructor
+    col7 = opty_amd.ConstraintCollocator(
+        tmp_dir=str(tmp_path/'sixth'), verify_builds='off', **kw)
+    assert col7.hip is not None
 
 
 FROZEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..',
