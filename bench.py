@@ -273,8 +273,7 @@ def config3_shards(kw, dev, iters, whole_ms):
                                         sjac, a, b, iters) for _ in range(3))
             out['shard_1of%d' % world] = dict(
                 nodes=b - a, fused_ms=ms, speedup_vs_whole=whole_ms/ms,
-                fused_pays=not sh.desc.get('fused_loses'),
-                build_check=_build_check(shard))
+                build_check=_build_check(shard), **_routing(sh, b - a))
             sh.close()
             del scon, sjac
         except Exception as exc:         # noqa: the headline must survive
@@ -291,8 +290,27 @@ def _build_check(col):
     v = getattr(col, '_build_verdict', None)
     if not v:
         return None
-    return {k: v.get(k) for k in ('ok', 'referee', 'worst', 'nodes',
-                                  'replacement') if v.get(k) is not None}
+    # (isa_exec_copies: what the static ISA check found in the build in
+    # use, {} = clean; isa_replaced: it replaced a build with such copies;
+    # vector_spills_in_service: spilling kernels an entry point can launch
+    # -- must be {}; banned_kernels: spilling kernels no entry point
+    # launches)
+    return {k: v.get(k) for k in (
+        'ok', 'referee', 'referee_version', 'worst', 'nodes', 'replacement',
+        'isa_exec_copies', 'isa_replaced', 'banned_kernels',
+        'vector_spills_in_service') if v.get(k) is not None}
+
+
+def _routing(hip, nodes=None):
+    """What the handle's entry points launch for this launch size, as the
+    handle measured it on this device (``opty_hip_routing``)."""
+    r = hip.routing(nodes)
+    out = dict(routing=r['routing'], fused_pays=not r['fused_loses'],
+               jac_via_fused=r['jac_via_fused'])
+    if 'ms' in r:
+        out['calibration_ms'] = {k: round(float(v), 6)
+                                 for k, v in r['ms'].items()}
+    return out
 
 
 def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
@@ -312,24 +330,28 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
     # 'opty_conjac_kernel' is the fused kernel itself in that case
     whats = [(hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC, 'opty_jac'),
              (hb.EVAL_FUSED, 'opty_conjac')]
-    if hip.desc.get('fused_loses'):
-        whats.append((hb.EVAL_FUSED_KERNEL, 'opty_conjac_kernel'))
     for what, label in whats:
         hip.time_eval(what, free, con, jac, max(3, iters//4))
         res[label] = hip.time_eval(what, free, con, jac, iters)
+    route = _routing(hip)
+    if not route['fused_pays'] and not hip.desc['routing'] & \
+            hb.ROUTE_NO_FUSED_KERNEL:
+        hip.time_eval(hb.EVAL_FUSED_KERNEL, free, con, jac,
+                      max(3, iters//4))
+        res['opty_conjac_kernel'] = hip.time_eval(
+            hb.EVAL_FUSED_KERNEL, free, con, jac, iters)
     nbytes = 8.0*(col.num_free + col.num_constraints + hip.nnz)
     serial = res['opty_con'] + res['opty_jac']
     out[name] = dict(
         nodes=col.num_collocation_nodes, nnz=hip.nnz, kernel_ms=res,
         fused_algorithmic_bytes=nbytes,
         fused_hbm_frac=nbytes/(res['opty_conjac']*1e-3)/1e9/HBM_PEAK_GBS,
-        fused_pays=not hip.desc.get('fused_loses'),
         evals_per_s=1e3/res['opty_conjac'],
         serial_evals_per_s=1e3/serial,
         # (every launch of this entry reads ONE free vector; the headline
         # rotates four -- 1-2 % of the bytes of a write stream)
         free_vectors=1,
-        build_check=_build_check(col))
+        build_check=_build_check(col), **route)
     if name in SPECIALISED_ENTRIES:
         # opt-in: node-invariant values as literals of the kernels
         # (ConstraintCollocator(specialize_parameters=True): for solves with
@@ -371,7 +393,7 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
         out[name]['shard_1of8'] = dict(
             nodes=b - a, fused_ms=ms,
             speedup_vs_whole=res['opty_conjac']/ms,
-            build_check=_build_check(shard))
+            build_check=_build_check(shard), **_routing(sh, b - a))
         sh.close()
         del scon
     if name == 'config2_pendulum':
@@ -752,14 +774,19 @@ def main():
         # columns of the launch's nodes once, write the outputs once
         jac_bytes = free_bytes + 8.0*P*cnt
         con_bytes = free_bytes + 8.0*M*cnt
-        if args.serial:
+        route = _routing(hip, cnt)
+        if args.serial or not route['fused_pays']:
+            # (two launches per step -- asked for, or because the handle
+            # measured opty_con + opty_jac faster than the fused kernel on
+            # this device: the Jacobian kernel is the dominant one)
             dom, dom_ms, dom_bytes = 'opty_jac', jac_ms, jac_bytes
         else:
             dom, dom_ms = 'opty_conjac', fused_ms
             dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
         achieved = dom_bytes/(dom_ms*1e-3)/1e9
         kmeta = col._kernel_meta['kernels'][
-            'jac' if args.serial else 'conjac']
+            'jac' if dom == 'opty_jac' and not route['jac_via_fused']
+            else 'conjac']
         traffic = lookup_traffic(kmeta['sha']) \
             if (world == 1 and args.nodes == 100000) else None
         value = args.steps*(1 if strong else world)/elapsed
@@ -795,6 +822,7 @@ def main():
                 'prewarm_ms': args.prewarm_ms,
                 'code_object_sha': col._kernel_meta['sha'][:16],
                 'build_check': _build_check(col),
+                'routing': route,
                 'kernel_sha': kmeta['sha'][:16],
                 'jac_waves_per_block': hip.desc['jac_wgs_per_block'] *
                 hip.desc['jac_waves_per_wg'],

@@ -60,6 +60,22 @@ enum { OPTY_HIP_EVAL_CON = 0, OPTY_HIP_EVAL_JAC = 1, OPTY_HIP_EVAL_PAIR = 2,
         * (measurement tools) */
        OPTY_HIP_EVAL_FUSED_KERNEL = 4 };
 
+/* opty_hip_desc.routing.
+ * CALIBRATE: at the first OPTY_HIP_EVAL_FUSED / OPTY_HIP_EVAL_JAC launch of
+ *   every launch size the handle times opty_conjac, opty_con and opty_jac on
+ *   its own device (hipEvents, a few launches into the caller's buffers) and
+ *   from then on launches the faster of fused kernel / pair and of opty_jac /
+ *   fused kernel; desc.fused_loses / desc.jac_via_fused (the launch plan's
+ *   flags, measured on the tuner's box) only break ties (1 %).
+ *   OPTY_HIP_ROUTING=plan in the environment keeps the flags as they are.
+ * NO_JAC_KERNEL / NO_FUSED_KERNEL: that kernel of the module must never be
+ *   launched (the build found it to spill vector registers):
+ *   EVAL_JAC and the pair go through the fused kernel / EVAL_FUSED issues
+ *   opty_con + opty_jac.  Not both. */
+#define OPTY_HIP_ROUTE_CALIBRATE 1
+#define OPTY_HIP_ROUTE_NO_JAC_KERNEL 2
+#define OPTY_HIP_ROUTE_NO_FUSED_KERNEL 4
+
 #define OPTY_HIP_LAYOUT_COO 0
 #define OPTY_HIP_LAYOUT_CSR 1
 #define OPTY_HIP_LAYOUT_SEGMENTED 2
@@ -129,6 +145,9 @@ typedef struct opty_hip_desc {
                              time a one-wave-per-item dispatch leaves between
                              and after the waves                              */
     int32_t fused_persist; /* the same for opty_conjac                        */
+    int32_t routing;      /* OPTY_HIP_ROUTE_* bits: which of the module's
+                             kernels the entry points may launch, and whether
+                             the handle measures the choice itself           */
     float jac_class_cost[OPTY_HIP_MAX_CLASSES];   /* relative duration of the
                              wave of strip class g (any unit; measured by the
                              launch plan's tuner or the printer's estimate);
@@ -138,10 +157,10 @@ typedef struct opty_hip_desc {
 
 /* Version of this header's structs and signatures; opty_hip_abi_version()
  * returns the one the library was built from.  A client built against another
- * version must not call the library: the descriptor grew in 5 and 6, and
+ * version must not call the library: the descriptor grew in 5, 6 and 7, and
  * opty_hip_eval_jac_persistent / opty_hip_shard_jac_to_host took their `fresh`
  * argument in 4. */
-#define OPTY_HIP_ABI_VERSION 6
+#define OPTY_HIP_ABI_VERSION 7
 int opty_hip_abi_version(void);
 
 /* Build verification aid: leaves `pattern` in every vector / accumulation /
@@ -389,6 +408,19 @@ int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
                              int64_t con_stride, double *jac,
                              int64_t node_begin, int64_t node_end,
                              int32_t iters, float *ms_per_iter);
+
+/* What the entry points launch for a launch of `node_count` constraint nodes
+ * (opty_hip_desc.routing): *calibrated = 1 when the handle has measured that
+ * launch size on its device (ms3[0..2] = per-launch ms of opty_conjac,
+ * opty_con, opty_jac as measured), 0 when the launch plan's flags are still
+ * in force; *fused_loses = 1: OPTY_HIP_EVAL_FUSED issues opty_con + opty_jac;
+ * *jac_via_fused = 1: OPTY_HIP_EVAL_JAC launches opty_conjac.  Any output
+ * pointer may be null.  The reference calls its two callbacks separately
+ * (opty/direct_collocation.py:498-562): whichever kernel serves them, the
+ * values are those of the same expressions. */
+int opty_hip_routing(opty_hip_problem *p, int64_t node_count,
+                     int32_t *calibrated, int32_t *fused_loses,
+                     int32_t *jac_via_fused, float *ms3);
 
 /* ---- objective and objective gradient -------------
  * Device counterpart of create_objective_function (opty/utils.py:329-470):

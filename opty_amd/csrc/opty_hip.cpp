@@ -779,8 +779,18 @@ struct Schedule {
     int npw = 0;
 };
 
+// Which kernels the entry points launch for one launch size, measured on
+// the device the handle lives on (opty_hip_desc.routing, calibrate_route).
+struct Route {
+    long long nblk = -1;
+    bool fused_loses = false, jac_via_fused = false;
+    float ms_fused = 0.f, ms_con = 0.f, ms_jac = 0.f;   // per launch
+};
+
 struct opty_hip_problem {
     std::vector<Schedule> sched_jac, sched_fused;
+    std::vector<Route> routes;
+    hipEvent_t ev_cal0 = nullptr, ev_cal1 = nullptr;
     opty_hip_desc d{};
     hipModule_t module = nullptr;
     hipFunction_t k_con = nullptr, k_jac = nullptr, k_conjac = nullptr,
@@ -1053,6 +1063,124 @@ int launch_instance(opty_hip_problem *p, const double *free_, double *con_tail,
 template <typename T>
 int ensure(T **ptr, size_t count);
 
+bool routing_enabled() {
+    // OPTY_HIP_ROUTING=plan: the launch plan's flags as they are (A/B runs)
+    const char *e = getenv("OPTY_HIP_ROUTING");
+    return !(e && !strcmp(e, "plan"));
+}
+
+// Average duration (ms) of one issue of `fn` on the handle's stream: one
+// untimed issue, then the best of three timed batches (hipEvents; batches
+// long enough for the event resolution).
+template <typename Fn>
+int time_issue(opty_hip_problem *p, Fn fn, float *ms_out) {
+    if (int rc = fn()) return rc;
+    int n = 2;
+    float best = 1e30f;
+    for (int round = 0; round < 3; ++round) {
+        HIP_TRY(hipEventRecord(p->ev_cal0, p->stream));
+        for (int i = 0; i < n; ++i)
+            if (int rc = fn()) return rc;
+        HIP_TRY(hipEventRecord(p->ev_cal1, p->stream));
+        HIP_TRY(hipEventSynchronize(p->ev_cal1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev_cal0, p->ev_cal1));
+        if (ms/n < best) best = ms/n;
+        if (round == 0 && ms < 0.2f) {
+            const float per = ms/n > 1e-4f ? ms/n : 1e-4f;
+            const int want = (int)(0.25f/per) + 1;
+            n = want > 64 ? 64 : (want < n ? n : want);
+        }
+    }
+    *ms_out = best;
+    return 0;
+}
+
+// Measures, for the launch size of `rg`, the three kernels an entry point
+// can be served by -- opty_conjac, opty_con, opty_jac -- on the handle's own
+// device and stream, into the caller's buffers (the evaluation is a pure
+// function of `free`: writing a result twice is harmless; a missing
+// constraint vector is replaced by the handle's scratch), and decides
+//   fused_loses   : opty_con + opty_jac beat opty_conjac,
+//   jac_via_fused : opty_conjac beats opty_jac,
+// each against the launch plan's flag with 1 % + 0.3 us in favour of the flag
+// (two kernels within the resolution of the timer must not flip from handle
+// to handle).  A few launches, once per handle and launch size (VERDICT r05
+// item 2: the plan file's flags were measured on another box, and were wrong
+// on the driver's for two problems).
+int calibrate_route(opty_hip_problem *p, const double *free_, double *con,
+                    double *jac, const NodeRange &rg, Route *out) {
+    if (!p->ev_cal0) {
+        HIP_TRY(hipEventCreate(&p->ev_cal0));
+        HIP_TRY(hipEventCreate(&p->ev_cal1));
+    }
+    NodeRange cr = rg;
+    if (!con) {
+        if (int rc = ensure(&p->d_con_scratch, (size_t)p->num_con()))
+            return rc;
+        con = p->d_con_scratch + rg.begin;
+        cr.con_stride = p->ncon_nodes();
+    }
+    auto fused = [&] {
+        return launch(p, p->k_conjac, p->d.fused_wgs_per_block,
+                      64*p->d.fused_waves_per_wg, free_, con, jac, cr, false,
+                      p->d.fused_persist, &p->sched_fused,
+                      p->d.fused_class_cost);
+    };
+    auto conk = [&] {
+        return launch(p, p->k_con, p->d.con_wgs_per_block,
+                      64*p->d.con_waves_per_wg, free_, con, nullptr, cr);
+    };
+    auto jack = [&] {
+        return launch(p, p->k_jac, p->d.jac_wgs_per_block,
+                      64*p->d.jac_waves_per_wg, free_, nullptr, jac, cr,
+                      false, p->d.jac_persist, &p->sched_jac,
+                      p->d.jac_class_cost);
+    };
+    Route r;
+    r.nblk = (rg.end - rg.begin + 63)/64;
+    if (int rc = time_issue(p, fused, &r.ms_fused)) return rc;
+    if (int rc = time_issue(p, conk, &r.ms_con)) return rc;
+    if (int rc = time_issue(p, jack, &r.ms_jac)) return rc;
+    const float pair = r.ms_con + r.ms_jac;
+    const bool plan_loses = p->d.fused_loses != 0;
+    r.fused_loses = plan_loses ? !(r.ms_fused < pair*0.99f - 3e-4f)
+                               : (pair < r.ms_fused*0.99f - 3e-4f);
+    const bool plan_via = p->d.jac_via_fused != 0;
+    r.jac_via_fused = !r.fused_loses &&
+        (plan_via ? !(r.ms_jac < r.ms_fused*0.99f - 3e-4f)
+                  : (r.ms_fused < r.ms_jac*0.99f - 3e-4f));
+    static const bool trace = getenv("OPTY_HIP_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "opty_hip: routing of %lld-block launches: opty_conjac "
+                "%.4f ms, opty_con %.4f + opty_jac %.4f = %.4f ms -> "
+                "fused_loses %d (plan %d), jac_via_fused %d (plan %d)\n",
+                r.nblk, r.ms_fused, r.ms_con, r.ms_jac, pair,
+                (int)r.fused_loses, (int)plan_loses, (int)r.jac_via_fused,
+                (int)plan_via);
+    *out = r;
+    return 0;
+}
+
+// The route of the launch size of `rg`; measured at its first use.  *out
+// stays null when it cannot be measured (no Jacobian buffer: never asked).
+int route_for(opty_hip_problem *p, const double *free_, double *con,
+              double *jac, const NodeRange &rg, const Route **out) {
+    const long long nblk = (rg.end - rg.begin + 63)/64;
+    for (const Route &r : p->routes)
+        if (r.nblk == nblk) {
+            *out = &r;
+            return 0;
+        }
+    if (!jac || nblk == 0) return 0;
+    Route r;
+    if (int rc = calibrate_route(p, free_, con, jac, rg, &r)) return rc;
+    if (p->routes.size() >= 16) p->routes.erase(p->routes.begin());
+    p->routes.push_back(r);
+    *out = &p->routes.back();
+    return 0;
+}
+
 int eval_device(opty_hip_problem *p, int what, const double *free_,
                 double *con, double *jac, const NodeRange &rg,
                 bool with_inst) {
@@ -1070,15 +1198,48 @@ int eval_device(opty_hip_problem *p, int what, const double *free_,
     // problem as much as its evaluation).
     const bool tails = with_inst && p->d.num_inst > 0;
     const bool folded = tails && p->d.inst_folded;
-    // the launch plan measured the fused kernel slower than the two it
-    // replaces (opty_hip_desc.fused_loses): issue those
-    if (what == OPTY_HIP_EVAL_FUSED && p->d.fused_loses)
+    // Which of the module's kernels serve this entry point.  The launch
+    // plan's flags (measured on the tuner's box) are the starting point;
+    // with OPTY_HIP_ROUTE_CALIBRATE the handle measures the candidates on
+    // ITS device at the first launch of every size and keeps the faster
+    // (calibrate_route); a kernel the build marked unusable (it spills
+    // vector registers: OPTY_HIP_ROUTE_NO_*) is never launched.
+    bool fused_loses = p->d.fused_loses != 0;
+    bool jac_via_fused = p->d.jac_via_fused != 0;
+    const int banned = p->d.routing & (OPTY_HIP_ROUTE_NO_JAC_KERNEL |
+                                       OPTY_HIP_ROUTE_NO_FUSED_KERNEL);
+    if ((p->d.routing & OPTY_HIP_ROUTE_CALIBRATE) && !banned &&
+        routing_enabled() &&
+        (what == OPTY_HIP_EVAL_FUSED || what == OPTY_HIP_EVAL_JAC)) {
+        const Route *rt = nullptr;
+        if (int rc = route_for(p, free_, con, jac, rg, &rt)) return rc;
+        if (rt) {
+            fused_loses = rt->fused_loses;
+            jac_via_fused = rt->jac_via_fused;
+        }
+    }
+    if (banned & OPTY_HIP_ROUTE_NO_JAC_KERNEL) {
+        // opty_jac is out: the fused kernel serves EVAL_JAC (constraint
+        // values to scratch) and the pair
+        fused_loses = false;
+        jac_via_fused = true;
+        if (what == OPTY_HIP_EVAL_PAIR) what = OPTY_HIP_EVAL_FUSED;
+    }
+    if (banned & OPTY_HIP_ROUTE_NO_FUSED_KERNEL) {
+        if (what == OPTY_HIP_EVAL_FUSED_KERNEL)
+            return fail("the fused kernel of this module is marked unusable "
+                        "(opty_hip_desc.routing)");
+        fused_loses = true;
+        jac_via_fused = false;
+    }
+    // the fused kernel was measured slower than the two it replaces: issue
+    // those
+    if (what == OPTY_HIP_EVAL_FUSED && fused_loses)
         what = OPTY_HIP_EVAL_PAIR;
     if (what == OPTY_HIP_EVAL_FUSED_KERNEL) what = OPTY_HIP_EVAL_FUSED;
-    // ... or the fused kernel faster than the Jacobian-only one
-    // (opty_hip_desc.jac_via_fused): its constraint values go to scratch
-    if (what == OPTY_HIP_EVAL_JAC && p->d.jac_via_fused &&
-        !p->d.fused_loses) {
+    // ... or faster than the Jacobian-only one: its constraint values go to
+    // scratch
+    if (what == OPTY_HIP_EVAL_JAC && jac_via_fused && !fused_loses) {
         if (int rc = ensure(&p->d_con_scratch, (size_t)p->num_con()))
             return rc;
         NodeRange sr{rg.begin, rg.end, p->ncon_nodes()};
@@ -1889,6 +2050,8 @@ int opty_hip_destroy(opty_hip_problem *p) {
     for (hipEvent_t e : p->chunk_events) (void)hipEventDestroy(e);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev_cal0) (void)hipEventDestroy(p->ev_cal0);
+    if (p->ev_cal1) (void)hipEventDestroy(p->ev_cal1);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     if (p->module) (void)hipModuleUnload(p->module);
@@ -2165,6 +2328,13 @@ static int time_impl(opty_hip_problem *p, int32_t what, const double *free_,
                                 nullptr, rg)) return rc;
         p->uni_dirty = false;
     }
+    // ... and the one-off calibration of the routing of this launch size
+    if ((p->d.routing & OPTY_HIP_ROUTE_CALIBRATE) && routing_enabled() &&
+        !(p->d.routing & ~OPTY_HIP_ROUTE_CALIBRATE) &&
+        (what == OPTY_HIP_EVAL_FUSED || what == OPTY_HIP_EVAL_JAC)) {
+        const Route *rt = nullptr;
+        if (int rc = route_for(p, free_, con, jac, rg, &rt)) return rc;
+    }
     HIP_TRY(hipEventRecord(p->ev0, p->stream));
     for (int it = 0; it < iters; ++it)
         if (int rc = eval_device(p, what, free_, con, jac, rg, with_inst))
@@ -2218,6 +2388,32 @@ int opty_hip_time_eval_shard(opty_hip_problem *p, int32_t what,
     return time_impl(p, what, free_, con, jac,
                      NodeRange{node_begin, node_end, con_stride}, false, iters,
                      ms_per_iter);
+}
+
+int opty_hip_routing(opty_hip_problem *p, int64_t node_count,
+                     int32_t *calibrated, int32_t *fused_loses,
+                     int32_t *jac_via_fused, float *ms3) {
+    if (!p) return fail("null handle");
+    if (node_count < 0) return fail("negative node count");
+    const long long nblk = (node_count + 63)/64;
+    const Route *hit = nullptr;
+    for (const Route &r : p->routes)
+        if (r.nblk == nblk) hit = &r;
+    const int banned = p->d.routing & (OPTY_HIP_ROUTE_NO_JAC_KERNEL |
+                                       OPTY_HIP_ROUTE_NO_FUSED_KERNEL);
+    bool fl = hit ? hit->fused_loses : p->d.fused_loses != 0;
+    bool jv = hit ? hit->jac_via_fused : p->d.jac_via_fused != 0;
+    if (banned & OPTY_HIP_ROUTE_NO_JAC_KERNEL) { fl = false; jv = true; }
+    if (banned & OPTY_HIP_ROUTE_NO_FUSED_KERNEL) { fl = true; jv = false; }
+    if (calibrated) *calibrated = hit ? 1 : 0;
+    if (fused_loses) *fused_loses = fl;
+    if (jac_via_fused) *jac_via_fused = jv && !fl;
+    if (ms3) {
+        ms3[0] = hit ? hit->ms_fused : 0.f;
+        ms3[1] = hit ? hit->ms_con : 0.f;
+        ms3[2] = hit ? hit->ms_jac : 0.f;
+    }
+    return 0;
 }
 
 int opty_hip_set_host_threads(int32_t count) {

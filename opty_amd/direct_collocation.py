@@ -16,6 +16,9 @@ follows the reference's rules so that ``constraints(free)``,
 """
 
 import logging
+import os
+
+import subprocess
 
 import numpy as np
 import sympy as sm
@@ -652,6 +655,57 @@ class ConstraintCollocator(object):
         return self._literal_values
 
     def _build_code_object(self, opt_level=None):
+        """The code object this collocator uses: :meth:`_build_spill_free`'s,
+        unless the static ISA check (``opty_amd.isa_check``: a vector
+        register copied into an accumulation register under a narrowed EXEC
+        and read back under a wider one -- the hipcc 7.2 fault of DESIGN.md
+        4.1 that is understood at the instruction) finds such a copy in one
+        of its kernels.  Then the same geometry printed with ``fast_trig=2``
+        (sincos behind a wave-uniform test: no EXEC-narrowing if / else on
+        the hot path, which is where the copies sit) is built, and used when
+        it is clean -- no such copy, no vector spills --, BEFORE any GPU time
+        is spent on either.  ``meta['isa_exec_copies']``
+        carries the count of the build in use; the referee judges it like
+        any other build."""
+        import copy
+        from . import isa_check
+        hsaco, meta = self._build_spill_free(opt_level)
+        banned = set(meta.get('banned_kernels', ()))
+        names = [k for k in ('opty_con', 'opty_jac', 'opty_conjac')
+                 if k not in banned]
+        try:
+            hits = isa_check.exec_copies(hsaco, names)
+        except (OSError, subprocess.SubprocessError) as err:
+            logger.warning('static ISA check of %s failed: %s', hsaco, err)
+            return hsaco, dict(meta, isa_exec_copies=None)
+        meta = dict(meta, isa_exec_copies=dict(hits))
+        base = self._built_options
+        if not hits or self._emit_options is not None or \
+                self._pinned_build() is not None or base is None or \
+                base.fast_trig == 2 or opt_level is not None:
+            return hsaco, meta
+        trial = copy.copy(base)
+        trial.fast_trig = 2
+        source, tmeta = self._emit(trial)
+        twin = self._compile(source)
+        spills = {k: v for k, v in hb.vgpr_spills(twin).items()
+                  if k not in banned}
+        thits = isa_check.exec_copies(twin, names)
+        if spills or thits:
+            logger.info('static ISA check: %s in %s; the uniform-sincos '
+                        'sibling is no better (copies %s, spills %s): kept',
+                        hits, os.path.basename(hsaco), thits, spills)
+            return hsaco, meta
+        logger.info('static ISA check: %s in %s: replaced by the uniform-'
+                    'sincos sibling %s (clean)', hits,
+                    os.path.basename(hsaco), os.path.basename(twin))
+        self._built_source, self._built_options = source, trial
+        keep = {k: meta[k] for k in ('banned_kernels', 'vector_spills')
+                if k in meta}
+        return twin, dict(tmeta, isa_exec_copies={}, isa_replaced=dict(hits),
+                          **keep)
+
+    def _build_spill_free(self, opt_level=None):
         """Emits and compiles this problem's module; returns ``(hsaco path,
         meta)``.  Unless the caller fixed the printer options, a build whose
         kernels spill VECTOR registers to scratch memory is not used (see
@@ -790,6 +844,23 @@ class ConstraintCollocator(object):
                     least = min(results, key=lambda r: sum(r[2].values()))
                     if sum(least[2].values()) < sum(best[2].values()):
                         best = least
+        if best[2] and set(best[2]) in ({'opty_jac'}, {'opty_conjac'}) and \
+                self._jacobian_layout in ('coo', 'csr'):
+            # ONE of the two Jacobian kernels spills whatever the cut, the
+            # other is clean (the biped's 6 250-node shard: opty_jac, 2
+            # registers): the spilling kernel is never launched -- the
+            # handle routes its entry point through the clean one
+            # (opty_hip_desc.routing: OPTY_HIP_ROUTE_NO_*), every wrong
+            # build of r03 was of this class.
+            banned = sorted(best[2])
+            logger.info('kernel %s spills vector registers whatever the cut '
+                        '(%s): it will not be launched, %s serves its entry '
+                        'point', banned[0], best[2],
+                        'opty_conjac' if banned == ['opty_jac']
+                        else 'opty_con + opty_jac')
+            self._built_source, self._built_options = best[3][0], best[4]
+            return best[0], dict(best[1], banned_kernels=banned,
+                                 vector_spills=dict(best[2]))
         if best[2]:
             # No cut is spill-free (a system larger than anything in the
             # zoo).  The wrong values of round 3 followed one stage of the
@@ -1084,7 +1155,13 @@ class ConstraintCollocator(object):
                        nodes=int(
                            min(self.num_collocation_nodes,
                                self._VERIFY_NODES)),
-                       kernels={k: list(v) for k, v in hot.items()})
+                       kernels={k: list(v) for k, v in hot.items()},
+                       isa_exec_copies=meta.get('isa_exec_copies'),
+                       isa_replaced=meta.get('isa_replaced'),
+                       banned_kernels=list(meta.get('banned_kernels', ())),
+                       vector_spills_in_service={
+                           k: v for k, v in hb.vgpr_spills(hsaco).items()
+                           if k not in meta.get('banned_kernels', ())})
         if not verdict['ok']:
             raise hb.BuildRejected(
                 'kernels of %s (%s) disagree with the expression DAG '
@@ -1255,8 +1332,15 @@ class ConstraintCollocator(object):
         problem's module on the first ``_VERIFY_NODES`` nodes: separate and
         fused launches, host buffers, no instance tails (scalar code)."""
         N, free = self._verification_inputs(seed, span)
-        desc = dict(self._descriptor(meta), N=N, num_inst=0, nnz_inst=0,
-                    num_inst_atoms=0, inst_folded=0)
+        # every entry point launches its OWN kernel here (no plan flags, no
+        # calibration: any of the three may serve a caller once the handle
+        # has measured them) -- except a kernel the build banned, which no
+        # entry point ever launches
+        base = self._descriptor(meta)
+        desc = dict(base, N=N, num_inst=0, nnz_inst=0,
+                    num_inst_atoms=0, inst_folded=0, fused_loses=0,
+                    jac_via_fused=0,
+                    routing=base['routing'] & ~hb.ROUTE_CALIBRATE)
         if self._jacobian_layout == 'varying_first':
             desc['layout'] = 0          # the kernels write node-major blocks
         h = hb.HipProblem(desc, hsaco)
@@ -1465,10 +1549,25 @@ class ConstraintCollocator(object):
             inst_folded=int(meta.get('inst_folded', False)),
             fused_loses=self._fused_loses(),
             jac_via_fused=self._plan_flag('jac_via_fused'),
+            routing=self._routing_bits(meta),
             jac_persist=meta['kernels']['jac'].get('persist', 0),
             fused_persist=meta['kernels']['conjac'].get('persist', 0),
             jac_class_cost=self._class_cost(meta, 'jac'),
             fused_class_cost=self._class_cost(meta, 'conjac'))
+
+    def _routing_bits(self, meta):
+        """``opty_hip_desc.routing``: the handle calibrates which kernels
+        serve ``EVAL_FUSED`` / ``EVAL_JAC`` on its own device (the plan's
+        ``fused_pays`` / ``jac_via_fused`` break ties; ``OPTY_HIP_ROUTING=
+        plan`` keeps them as they are), and never launches a kernel the
+        build marked unusable (``meta['banned_kernels']``)."""
+        bits = hb.ROUTE_CALIBRATE
+        banned = meta.get('banned_kernels', ())
+        if 'opty_jac' in banned:
+            bits |= hb.ROUTE_NO_JAC_KERNEL
+        if 'opty_conjac' in banned:
+            bits |= hb.ROUTE_NO_FUSED_KERNEL
+        return bits
 
     def _class_cost(self, meta, key):
         """Relative wave durations of a persistent kernel's strip classes

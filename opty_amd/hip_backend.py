@@ -29,11 +29,13 @@ DEFAULT_CACHE = os.path.join(_PKG, '_cache')
 ARCH = 'gfx950'
 
 #: OPTY_HIP_ABI_VERSION of include/opty_hip.h these bindings were written for
-ABI_VERSION = 6
+ABI_VERSION = 7
 HOST, DEVICE = 0, 1
 #: hipStreamLegacy: the null / legacy default stream (torch's default)
 STREAM_LEGACY = 1
 EVAL_CON, EVAL_JAC, EVAL_PAIR, EVAL_FUSED, EVAL_FUSED_KERNEL = 0, 1, 2, 3, 4
+#: opty_hip_desc.routing bits (include/opty_hip.h: OPTY_HIP_ROUTE_*)
+ROUTE_CALIBRATE, ROUTE_NO_JAC_KERNEL, ROUTE_NO_FUSED_KERNEL = 1, 2, 4
 
 
 class HipBackendError(RuntimeError):
@@ -304,7 +306,7 @@ class _Desc(ctypes.Structure):
             'jac_waves_per_wg', 'fused_wgs_per_block', 'con_wgs_per_block',
             'num_uniform', 'uniform_dynamic', 'device', 'fused_waves_per_wg',
             'con_waves_per_wg', 'layout', 'inst_folded', 'fused_loses',
-            'jac_via_fused', 'jac_persist', 'fused_persist')] + [
+            'jac_via_fused', 'jac_persist', 'fused_persist', 'routing')] + [
         ('jac_class_cost', ctypes.c_float*32),
         ('fused_class_cost', ctypes.c_float*32)]
 
@@ -413,6 +415,10 @@ _SIGNATURES = {
     'opty_hip_host_threads': (ctypes.c_int, []),
     'opty_hip_host_numa_node': (ctypes.c_int, [_P]),
     'opty_hip_host_placement': (ctypes.c_int, [_P, _P, _P]),
+    'opty_hip_routing': (ctypes.c_int, [
+        _P, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32),
+        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32),
+        ctypes.POINTER(ctypes.c_float)]),
     'opty_hip_time_eval_shard': (ctypes.c_int, [
         _P, ctypes.c_int32, _P, _P, ctypes.c_int64, _P, ctypes.c_int64,
         ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]),
@@ -816,6 +822,26 @@ class HipProblem(object):
             self._h, what, _ptr(free), _ptr(con), con_stride, _ptr(jac),
             node_begin, node_end, iters, ctypes.byref(ms)))
         return ms.value
+
+    def routing(self, nodes=None):
+        """What the entry points launch for launches of ``nodes`` constraint
+        nodes (default: the whole problem): ``opty_hip_routing`` -- a dict
+        with ``routing`` ('calibrated' once the handle has measured that
+        launch size on its device, else 'plan'), ``fused_loses``,
+        ``jac_via_fused`` and, when calibrated, the measured ``ms`` of
+        ``opty_conjac`` / ``opty_con`` / ``opty_jac``."""
+        if nodes is None:
+            nodes = self.desc['N'] - 1
+        cal, fl, jv = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        ms = (ctypes.c_float*3)()
+        _check(self._lib.opty_hip_routing(
+            self._h, int(nodes), ctypes.byref(cal), ctypes.byref(fl),
+            ctypes.byref(jv), ms))
+        out = dict(routing='calibrated' if cal.value else 'plan',
+                   fused_loses=bool(fl.value), jac_via_fused=bool(jv.value))
+        if cal.value:
+            out['ms'] = dict(opty_conjac=ms[0], opty_con=ms[1], opty_jac=ms[2])
+        return out
 
     def time_eval(self, what, free, con, jac, iters):
         ms = ctypes.c_float()

@@ -756,13 +756,66 @@ def test_unavoidable_spills_fall_back_to_the_safe_scheduler(monkeypatch,
         return real(source, *args, **kw)
     monkeypatch.setattr(hb, 'compile_module', spy)
     monkeypatch.setattr(hb, 'vgpr_spills',
-                        lambda hsaco, kernels=None: {'opty_conjac': 3})
+                        lambda hsaco, kernels=None: {'opty_conjac': 3,
+                                                     'opty_jac': 1})
     with caplog.at_level(logging.WARNING, logger='opty_amd'):
         hsaco, meta = col._build_code_object()
     assert calls[-1] == hb.SAFE_SCHEDULER_FLAGS
     assert all(c == () for c in calls[:-1])
     assert hsaco != plain and os.path.exists(hsaco)
     assert any('cross_check' in r.getMessage() for r in caplog.records)
+    assert not meta.get('banned_kernels')
+
+
+@pytest.mark.parametrize('spilling,bit', [
+    ('opty_jac', hb.ROUTE_NO_JAC_KERNEL),
+    ('opty_conjac', hb.ROUTE_NO_FUSED_KERNEL)])
+def test_one_spilling_jacobian_kernel_is_banned_not_shipped(
+        monkeypatch, caplog, spilling, bit):
+    """When ONE of the two Jacobian kernels spills vector registers whatever
+    the cut and the other is clean, the spilling one is never launched: the
+    build is used as it is, marked (``meta['banned_kernels']``), and the
+    descriptor tells the library to serve that entry point with the clean
+    kernel (``OPTY_HIP_ROUTE_NO_*``) -- no last-resort scheduler flags, no
+    spilling kernel in service (the biped's 6 250-node shard, r05)."""
+    import logging
+    col = ConstraintCollocator(**problems.build('msd_be_small'))
+    plain, _ = col._build_code_object()
+    calls = []
+    real = hb.compile_module
+
+    def spy(source, *args, **kw):
+        calls.append(tuple(kw.get('extra_flags', ())))
+        return real(source, *args, **kw)
+    monkeypatch.setattr(hb, 'compile_module', spy)
+    monkeypatch.setattr(hb, 'vgpr_spills',
+                        lambda hsaco, kernels=None: {spilling: 2})
+    with caplog.at_level(logging.WARNING, logger='opty_amd'):
+        hsaco, meta = col._build_code_object()
+    assert all(c == () for c in calls)          # no last-resort flags
+    assert meta['banned_kernels'] == [spilling]
+    assert meta['vector_spills'] == {spilling: 2}
+    assert not [r for r in caplog.records if r.levelno >= logging.WARNING]
+    bits = col._routing_bits(meta)
+    assert bits & bit and bits & hb.ROUTE_CALIBRATE
+    assert col._descriptor(meta)['routing'] == bits
+
+
+def test_real_biped_shard_bans_its_spilling_kernel():
+    """The build the bench line of r05 carried with a warning: the
+    seven-segment biped's 6 250-node launches, whose ``opty_jac`` spills two
+    vector registers at every cut.  It is banned; what stays in service is
+    spill-free."""
+    col = ConstraintCollocator(launch_nodes=6250,
+                               **problems.build('biped_small'))
+    hsaco, meta = col.prebuild()
+    banned = meta.get('banned_kernels', [])
+    in_service = {k: v for k, v in hb.vgpr_spills(hsaco).items()
+                  if k not in banned}
+    assert in_service == {}, in_service
+    if banned:
+        assert banned == ['opty_jac']
+        assert col._routing_bits(meta) & hb.ROUTE_NO_JAC_KERNEL
 
 
 def test_hand_set_workgroup_width_is_narrowed_to_the_lds():
