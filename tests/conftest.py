@@ -49,12 +49,27 @@ def pytest_terminal_summary(terminalreporter):
         tr.write_line('  %-44s rel %.2e   %.2f bound units   (%d entries)'
                       % (label[:44], st['worst_rel'],
                          st['worst_bound_units'], st['entries']))
+    # entries that met the bar only through the tolerance floor (they miss
+    # 1e-10 of their OWN value: cancellation), per label
+    floored = sorted(((k, v) for k, v in gu.STATS.items()
+                      if v.get('entries_passed_by_floor')),
+                     key=lambda kv: -kv[1]['entries_passed_by_floor'])
+    tr.write_line('parity: %d of %d labels have entries that pass only by '
+                  'the floor%s' % (len(floored), len(worst),
+                                   ':' if floored else ''))
+    for label, st in floored[:12]:
+        tr.write_line('  %-44s %7d of %d entries, worst rel %.2e%s'
+                      % (label[:44], st['entries_passed_by_floor'],
+                         st['entries'], st['worst_rel_passed_by_floor'],
+                         '' if st.get('floor_capped') else '  (floor NOT '
+                         'capped by the row maximum)'))
     out = os.path.join(REPO, 'gpurun_out')
     try:
         import torch
-        if torch.cuda.is_available():
-            os.makedirs(out, exist_ok=True)
-            with open(os.path.join(out, 'parity_stats.json'), 'w') as f:
-                json.dump(gu.STATS, f, indent=1, sort_keys=True)
+        gpu = torch.cuda.is_available()
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_stats.json' if gpu
+                               else 'parity_stats_cpu.json'), 'w') as f:
+            json.dump(gu.STATS, f, indent=1, sort_keys=True)
     except Exception:
         pass

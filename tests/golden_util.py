@@ -43,6 +43,39 @@ def error_bounds(col, free, nodes=None):
     return dag_interp.error_bounds(col, free, nodes)
 
 
+def caps_for(jac_ref, num_con, N1, M, C):
+    """``(con_cap, jac_cap)`` for whole output vectors: :func:`row_caps` of
+    the reference Jacobian's collocation part, no cap (inf) on the instance
+    tails (their bound is their own size)."""
+    jac_ref = np.asarray(jac_ref, dtype=float)
+    ccap, jcap = row_caps(jac_ref[:N1*M*C].reshape(N1, M, C))
+    return (np.concatenate((ccap.ravel(), np.full(num_con - N1*M, np.inf))),
+            np.concatenate((jcap.ravel(),
+                            np.full(len(jac_ref) - N1*M*C, np.inf))))
+
+
+def note_floor_only(what, err, desired, tol, rtol):
+    """STATS accounting for checks that do not go through
+    :func:`assert_close` (the fuzz tests: floor = rtol x row maximum of the
+    ORACLE's Jacobian, nothing from the product)."""
+    with np.errstate(all='ignore'):
+        rel = np.where(desired != 0, err/np.abs(desired), 0.0)
+    st = STATS.setdefault(what, dict(worst_rel=0.0, worst_bound_units=0.0,
+                                     entries=0, entries_passed_by_floor=0,
+                                     worst_rel_passed_by_floor=0.0,
+                                     floor_capped=True))
+    if not desired.size:
+        return
+    st['worst_rel'] = max(st['worst_rel'], float(np.nanmax(rel)))
+    st['entries'] += int(desired.size)
+    by_floor = (err > rtol*np.abs(desired)) & (err <= tol)
+    if by_floor.any():
+        st['entries_passed_by_floor'] += int(by_floor.sum())
+        st['worst_rel_passed_by_floor'] = max(
+            st['worst_rel_passed_by_floor'],
+            float(np.nanmax(np.where(by_floor, rel, 0.0))))
+
+
 def row_caps(jac_blocks):
     """Per-entry cap on the tolerance floor from the reference values
     themselves: ``max |entry|`` over the entry's equation row of its node's
@@ -100,11 +133,24 @@ def assert_close(actual, desired, rtol=1e-10, scale=None, what='',
                      if bound is not None else np.zeros(1))
         st = STATS.setdefault(what or '?', dict(worst_rel=0.0,
                                                 worst_bound_units=0.0,
-                                                entries=0))
+                                                entries=0,
+                                                entries_passed_by_floor=0,
+                                                worst_rel_passed_by_floor=0.0,
+                                                floor_capped=cap is not None))
         st['worst_rel'] = max(st['worst_rel'], float(np.nanmax(rel)))
         st['worst_bound_units'] = max(st['worst_bound_units'],
                                       float(np.nanmax(units)))
         st['entries'] += int(desired.size)
+        # entries that do NOT meet rtol of their own value and pass only
+        # because of the floor (cancellation inside the entry): how many,
+        # and how far off relative to themselves
+        by_floor = (err > rtol*np.abs(desired)) & (err <= tol)
+        if by_floor.any():
+            st['entries_passed_by_floor'] += int(by_floor.sum())
+            st['worst_rel_passed_by_floor'] = max(
+                st['worst_rel_passed_by_floor'],
+                float(np.nanmax(np.where(by_floor, rel, 0.0))))
+        st['floor_capped'] = bool(st['floor_capped'] and cap is not None)
     bad = ~(err <= tol)          # NaNs are bad
     if bad.any():
         with np.errstate(all='ignore'):

@@ -48,6 +48,9 @@ def _check(tag, seed, orc, con, jac, c_ref, j_ref):
         assert np.isfinite(got).all() and (err <= RTOL).all(), (
             tag, seed, what, k, got[k], want[k])
         worst = max(worst, float(err.max()) if err.size else 0.0)
+        import golden_util as gu
+        gu.note_floor_only('fuzz %s %s' % (tag, what), np.abs(got - want),
+                           want, RTOL*np.maximum(np.abs(want), ref), RTOL)
     _WORST.setdefault(tag, []).append(worst)
 
 

@@ -152,6 +152,50 @@ def test_oracle_matches_gallery_reference(name):
                                atol=1e-12*np.abs(z['jac']).max())
 
 
+#: the gallery problems whose parity leans on the tolerance floor (entries
+#: that cancel: VERDICT r05 "what's weak" 1) plus a sample of the others
+SECOND_OPINION = [k for k in (
+    'gallery_light_diffraction', 'gallery_one_legged_time_trial',
+    'gallery_light_diffraction__flipped',
+    'gallery_one_legged_time_trial__flipped', 'gallery_countersteer',
+    'gallery_pendulum_swing_up_fixed_duration', 'gallery_car_around_pylons')
+    if k in ORACLE_CASES]
+
+
+@pytest.mark.parametrize('name', SECOND_OPINION)
+def test_gallery_floors_have_an_oracle_second_opinion(name):
+    """The per-entry floors of the gallery comparisons come from a running
+    error analysis of the PRODUCT's DAG (``golden_util.error_bounds``).  A
+    numerically poor rewrite there could widen its own tolerance -- so the
+    floors are held to an independent measure on the problems where they
+    matter: the term magnitudes of the ORACLE's SymPy expressions
+    (``tests/oracle_bounds.py``).  No entry's bound may exceed 32 of them,
+    and the reference's values must sit inside their own term magnitudes."""
+    import opty_amd
+    import oracle_bounds
+    from oracle.collocation_oracle import OracleCollocator
+    meta, z, kw = gc.load(name)
+    if meta['kind'] != 'full':
+        pytest.skip('sampled record')
+    orc = OracleCollocator(name=name, **kw)
+    orc.generate_jacobian_function()(z['free'])
+    cmag, jmag = oracle_bounds.magnitudes(orc, z['free'])
+    col = opty_amd.ConstraintCollocator(**kw)
+    cb, jb = gu.error_bounds(col, z['free'])
+    N1, M, C = meta['N'] - 1, meta['M'], meta['C']
+    for bound, mag, ref, what in (
+            (cb[:M*N1], cmag, z['con'][:M*N1], 'con'),
+            (jb[:M*C*N1], jmag, z['jac'][:M*C*N1], 'jac')):
+        assert np.isfinite(mag).all(), what
+        assert (np.abs(ref) <= mag*(1 + 1e-12) + 1e-300).all(), what
+        ratio = float(np.max(bound/np.maximum(mag, 1e-300)))
+        gu.STATS.setdefault(name + ' ' + what + ' (second opinion)', dict(
+            worst_rel=0.0, worst_bound_units=0.0, entries=int(bound.size),
+            entries_passed_by_floor=0, worst_rel_passed_by_floor=0.0,
+            floor_capped=True))['bound_over_oracle_magnitude'] = ratio
+        assert (bound <= 32.0*mag + 1e-300).all(), (what, ratio)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', gc.NAMES)
 def test_gallery_hip(name):

@@ -142,10 +142,14 @@ def test_against_oracle_ragged(name, N):
         c_ref = orc.generate_constraint_function()(free)
         j_ref = orc.generate_jacobian_function()(free)
         cb, jb = gu.error_bounds(col, free)
+        # floors capped at 1e-10 of the largest entry of the entry's own
+        # block row of the ORACLE's Jacobian, as in test_golden_full
+        ccap, jcap = gu.caps_for(j_ref, len(c_ref), N - 1, orc.M, orc.C)
         gu.assert_close(col.generate_constraint_function()(free), c_ref,
-                        RTOL, what='ragged con', bound=cb)
+                        RTOL, what='ragged %s con' % name, bound=cb,
+                        cap=ccap)
         gu.assert_close(col.generate_jacobian_function()(free), j_ref, RTOL,
-                        what='ragged jac', bound=jb)
+                        what='ragged %s jac' % name, bound=jb, cap=jcap)
     r_ref, k_ref = orc.jacobian_indices()
     rows, cols = col.jacobian_indices()
     np.testing.assert_array_equal(rows, r_ref)
@@ -219,12 +223,16 @@ def test_shard_indices_and_values():
     j_ref = orc.generate_jacobian_function()(free)
     r_ref, k_ref = orc.jacobian_indices()
     P = orc.M*orc.C
+    # floor: 1e-10 of the largest entry of the entry's own block row
+    ccap, jcap = gu.row_caps(np.asarray(j_ref)[:P*(N - 1)].reshape(
+        N - 1, orc.M, orc.C))
+    jcap = jcap.reshape(N - 1, P)
     for rank in range(3):
         sh = ShardedCollocator(rank=rank, world_size=3, **kw)
         gu.assert_close(sh.constraints_local(free), c_ref[:, sh.a:sh.b],
-                        RTOL, what='con shard')
+                        RTOL, what='con shard', cap=ccap[:, sh.a:sh.b])
         gu.assert_close(sh.jacobian_local(free), j_ref[sh.a*P:sh.b*P], RTOL,
-                        what='jac shard')
+                        what='jac shard', cap=jcap[sh.a:sh.b].ravel())
         rows, cols = sh.jacobian_indices_local()
         np.testing.assert_array_equal(rows, r_ref[sh.a*P:sh.b*P])
         np.testing.assert_array_equal(cols, k_ref[sh.a*P:sh.b*P])
@@ -246,10 +254,13 @@ def test_callable_known_trajectory():
         col.generate_jacobian_function()
     for seed in (1, 2):
         free = problems.make_free(col.num_free, seed=seed)
-        gu.assert_close(con(free), orc.generate_constraint_function()(free),
-                        RTOL, what='con')
-        gu.assert_close(jac(free), orc.generate_jacobian_function()(free),
-                        RTOL, what='jac')
+        c_ref = orc.generate_constraint_function()(free)
+        j_ref = orc.generate_jacobian_function()(free)
+        ccap, jcap = gu.caps_for(j_ref, len(c_ref), N - 1, orc.M, orc.C)
+        gu.assert_close(con(free), c_ref, RTOL, what='callable con',
+                        cap=ccap)
+        gu.assert_close(jac(free), j_ref, RTOL, what='callable jac',
+                        cap=jcap)
 
 
 def test_parameter_and_interval_updates_refresh_invariants():
@@ -269,8 +280,10 @@ def test_parameter_and_interval_updates_refresh_invariants():
     col.hip.set_interval(0.037)
     kw2 = dict(kw, known_parameter_map=new_map, node_time_interval=0.037)
     orc = OracleCollocator(name='pend3_link_midpoint', **kw2)
-    gu.assert_close(jac(free), orc.generate_jacobian_function()(free), RTOL,
-                    what='jac after update')
+    j_ref = orc.generate_jacobian_function()(free)
+    _, jcap = gu.caps_for(j_ref, orc.M*89, 89, orc.M, orc.C)
+    gu.assert_close(jac(free), j_ref, RTOL, what='jac after update',
+                    cap=jcap)
 
 
 def test_known_maps_are_re_read_on_every_call():
