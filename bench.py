@@ -461,12 +461,20 @@ def host_path(kw, dev_index, reps=15):
             out['jac_dense_copy'] = med(
                 lambda f: col.hip.eval_jac(f, dense, hb.HOST), frees)
             del dense
-            from opty_amd.codegen.program import varying_copies
+            from opty_amd.codegen.program import (varying_copies,
+                                                   scaled_copies)
             unique, copies = varying_copies(col._build_program())
             out['varying_entries_per_block'] = len(unique) + len(copies)
-            # ... of which only the distinct expressions cross PCIe
-            out['moved_entries_per_block'] = len(unique)
+            # ... of which only the distinct expressions cross PCIe (r05),
+            # and of those only one per group of node-invariant multiples
+            # of the same per-node expression (r06)
+            out['moved_entries_per_block_r05'] = len(unique)
+            moved = len(scaled_copies(col._build_program())[0]) \
+                if getattr(col, '_copy_chains', None) else len(unique)
+            out['moved_entries_per_block'] = moved
             out['host_threads'] = hb.host_threads()
+            ncn = col.num_collocation_nodes - 1
+            pcie = {'h2d_bytes': 8*col.num_free, 'd2h_bytes': 8*moved*ncn}
         # (the host scatter verifies its thread placement over the first
         # calls with every new vector -- opty_hip.cpp ScatterPool::feedback;
         # they are warm-up, for each of the three collocators)
@@ -487,6 +495,40 @@ def host_path(kw, dev_index, reps=15):
     # regression guard: the reference-ordered default layout
     # must stay within 15 % of the scatter-free opt-in layout, which sits on
     # the PCIe link
+    # The host path's own roofline: the bytes one jacobian(free) moves over
+    # the link against what the link does on THIS box (page-locked
+    # hipMemcpy of 256 MB either way, best of 5).  `frac` = the download of
+    # the moved entries -- 92 % of the bytes -- at the measured device-to-
+    # host rate over the median call; the upload of `free` rides the other
+    # direction of the link.
+    try:
+        n = 32 << 20
+        hbuf = hb.pinned_empty(n)
+        hbuf[:] = 1.0
+        dbuf = hb.DeviceVector(hbuf[:1], dev_index)
+        dbuf.close()
+        lib = hb.load_library()
+        dptr = lib.opty_hip_device_alloc(dev_index, 8*n)
+        rates = {}
+        for tag, kind, dst, src in (('h2d', 0, dptr, hbuf.ctypes.data),
+                                    ('d2h', 1, hbuf.ctypes.data, dptr)):
+            ts = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                hb._check(lib.opty_hip_memcpy(dst, src, 8*n, kind))
+                ts.append(time.perf_counter() - t0)
+            rates[tag] = 8*n/min(ts[1:])/1e9
+        lib.opty_hip_device_free(dptr)
+        del hbuf
+        pcie['link_GBps'] = rates
+        pcie['d2h_GBps_achieved'] = pcie['d2h_bytes']/(out['jac']*1e-3)/1e9
+        pcie['frac'] = pcie['d2h_GBps_achieved']/rates['d2h']
+        pcie['frac_best_call'] = pcie['d2h_bytes']/(
+            out['jac_min']*1e-3)/1e9/rates['d2h']
+        pcie['bound_ms'] = 1e3*pcie['d2h_bytes']/(rates['d2h']*1e9)
+    except Exception as exc:             # noqa: secondary figure
+        pcie['error'] = '%s: %s' % (type(exc).__name__, str(exc)[:200])
+    out['pcie'] = pcie
     out['jac_guard'] = {
         'ok': bool(out['jac'] <= 1.15*out['jac_varying_first']),
         'ratio': out['jac']/out['jac_varying_first'], 'limit': 1.15}

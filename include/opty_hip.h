@@ -279,6 +279,16 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
  * list. */
 int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
                               const int32_t *src, int32_t count);
+/* The same with a factor per copy: the host threads fill entry dst[k] with
+ * scale[k] x entry src[k] of the same block -- varying entries that are a
+ * node-invariant multiple of another varying entry (c_1 X and c_2 X over the
+ * same per-node expression X: scale = c_1/c_2, computed by the caller from the
+ * known parameters and set again when those change) do not cross PCIe either.
+ * scale == NULL: plain copies.  A factor of exactly 1.0 reproduces the source
+ * bit for bit. */
+int opty_hip_set_entry_copies_scaled(opty_hip_problem *p, const int32_t *dst,
+                                     const int32_t *src, const double *scale,
+                                     int32_t count);
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free,
                                  double *jac, int32_t fresh);
 /* ---- OPTY_HIP_LAYOUT_SEGMENTED: a host-visible Jacobian without a scatter ---

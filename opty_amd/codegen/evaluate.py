@@ -115,9 +115,57 @@ def evaluate_uniform(dag, roots, scalar):
                 v = a[2] if _REL[args[0]](a[0], a[1]) else a[3]
             else:
                 v = _UNARY[op](a[0])
-        except (ValueError, ZeroDivisionError):
-            v = float('nan')
-        except OverflowError:
-            v = float('inf')
+        except (ValueError, ZeroDivisionError, OverflowError) as exc:
+            v = _ieee_result(op, a, exc)
         vals[i] = float(v)
     return vals
+
+
+def _ieee_result(op, a, exc):
+    """What C's libm (and the device's) returns where Python raises: a pole
+    gives a SIGNED infinity (``log(0) = -inf``, ``pow(0, -1) = +inf``,
+    ``atanh(-1) = -inf``, ``lgamma`` / ``tgamma`` at their poles), an overflow
+    the infinity of the result's sign (``sinh(-800) = -inf``, ``pow(-10, 301)
+    = -inf``), a domain error NaN (every overflow used to map to
+    +inf and every ValueError to NaN)."""
+    inf, nan = float('inf'), float('nan')
+    x = a[0]
+    if any(v != v for v in a):
+        return nan
+    if op in ('log', 'log2', 'log10'):
+        return -inf if x == 0.0 else nan
+    if op == 'log1p':
+        return -inf if x == -1.0 else nan
+    if op == 'atanh':
+        return math.copysign(inf, x) if abs(x) == 1.0 else nan
+    if op in ('exp', 'exp2', 'expm1', 'cosh'):
+        return inf if isinstance(exc, OverflowError) else nan
+    if op == 'sinh':
+        return math.copysign(inf, x) if isinstance(exc, OverflowError) \
+            else nan
+    if op == 'tgamma':
+        if isinstance(exc, OverflowError):
+            return inf
+        if x == 0.0:
+            return math.copysign(inf, x)
+        return nan                      # negative integers: C gives NaN
+    if op == 'lgamma':
+        return inf                      # poles at 0, -1, -2 ...: +inf
+    if op in (ir.POW, ir.POWI):
+        b = a[1] if op == ir.POW else None
+        if op == ir.POWI:
+            # (Python floats do not raise on multiplication: unreachable,
+            # kept for completeness)
+            return inf
+        if x == 0.0 and b < 0.0:
+            # pow(+-0, negative): +-inf for odd integers, +inf otherwise
+            odd = b == int(b) and int(b) % 2 != 0
+            return math.copysign(inf, x) if odd else inf
+        if isinstance(exc, OverflowError):
+            odd = b == int(b) and int(b) % 2 != 0
+            return -inf if (x < 0.0 and odd) else inf
+        return nan                      # negative base, fractional exponent
+    if isinstance(exc, OverflowError):
+        return inf
+    return nan
+

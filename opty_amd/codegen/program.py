@@ -232,14 +232,9 @@ def _column_key(n, q, method):
     return key
 
 
-def varying_entries(prog):
-    """Stored block entries whose value can differ between two evaluations
-    with the same known parameters and (fixed) node time interval: those that
-    depend on a trajectory value, an unknown parameter or a free interval.
-    The rest -- for the 10-link pendulum 660 of 990: the reference's
-    structural zeros, +-1, +-1/h, products of masses and lengths
-    (``opty/direct_collocation.py:2589-2593`` keeps them all in the value
-    vector) -- are the same at every node and every call."""
+def _static_tester(prog):
+    """``is_static(node)``: the node's value is the same at every node and
+    every call with the same known parameters and (fixed) interval."""
     dag = prog.dag
     static = {}
 
@@ -249,6 +244,7 @@ def varying_entries(prog):
             i = stack.pop()
             if i in static:
                 if not static[i]:
+                    static[root] = False
                     return False
                 continue
             if dag.op[i] == ir.INPUT:
@@ -257,21 +253,29 @@ def varying_entries(prog):
                       (kind == 'h' and prog.h[0] == 'fixed'))
                 static[i] = ok
                 if not ok:
+                    static[root] = False
                     return False
                 continue
             if not dag.uni[i]:
                 static[i] = False
+                static[root] = False
                 return False
             stack.extend(dag.operands(i))
+        static[root] = True
         return True
+    return is_static
 
-    out = []
-    for e, node in enumerate(prog.jac_out):
-        ok = is_static(node)
-        static[node] = ok
-        if not ok:
-            out.append(e)
-    return out
+
+def varying_entries(prog):
+    """Stored block entries whose value can differ between two evaluations
+    with the same known parameters and (fixed) node time interval: those that
+    depend on a trajectory value, an unknown parameter or a free interval.
+    The rest -- for the 10-link pendulum 660 of 990: the reference's
+    structural zeros, +-1, +-1/h, products of masses and lengths
+    (``opty/direct_collocation.py:2589-2593`` keeps them all in the value
+    vector) -- are the same at every node and every call."""
+    is_static = _static_tester(prog)
+    return [e for e, node in enumerate(prog.jac_out) if not is_static(node)]
 
 
 def varying_copies(prog):
@@ -293,4 +297,77 @@ def varying_copies(prog):
             first[node] = e
             unique.append(e)
     return unique, copies
+
+
+def scaled_copies(prog):
+    """:func:`varying_copies` taken one step further: varying entries that
+    are a NODE-INVARIANT multiple of another varying entry -- ``c_1 X`` and
+    ``c_2 X`` with the same per-node expression ``X`` and factors that depend
+    on known parameters / the fixed interval only (a mass-matrix partial in
+    the current node's column and, differently scaled, in another row) -- need
+    not both cross PCIe: the host fills ``dst = (c_dst/c_src) src``.
+
+    Returns ``(unique, copies)``: ``unique`` ascending entry numbers that are
+    moved; ``copies`` a list of ``(dst, src, num, den)`` sorted by ``dst``,
+    ``src`` in ``unique``, ``num`` / ``den`` the factor chains of dst / src --
+    lists of ``('neg',)``, ``('mul', node)``, ``('div', node)`` over static
+    DAG nodes, so that ``dst = prod(num)/prod(den) * src`` (:func:`chain_value`
+    evaluates them for given known values; exact duplicates have two empty
+    chains).  For the 10-link pendulum: 275 -> 269 moved entries (the
+    numerical rank of the 275 as functions of the node values is 266: what
+    ANY linear reconstruction could reach)."""
+    dag = prog.dag
+    is_static = _static_tester(prog)
+
+    def strip(i):
+        chain = []
+        while True:
+            op = dag.op[i]
+            if op == ir.NEG:
+                chain.append(('neg',))
+                i = dag.args[i][0]
+                continue
+            if op == ir.MUL:
+                a, b = dag.args[i]
+                if is_static(a) and not is_static(b):
+                    chain.append(('mul', a))
+                    i = b
+                    continue
+                if is_static(b) and not is_static(a):
+                    chain.append(('mul', b))
+                    i = a
+                    continue
+            if op == ir.DIV:
+                a, b = dag.args[i]
+                if is_static(b) and not is_static(a):
+                    chain.append(('div', b))
+                    i = a
+                    continue
+            return chain, i
+
+    base = {}                  # core node -> (entry, its chain)
+    unique, copies = [], []
+    for e in varying_entries(prog):
+        chain, core = strip(prog.jac_out[e])
+        if core in base:
+            src, den = base[core]
+            copies.append((e, src, chain, den))
+        else:
+            base[core] = (e, chain)
+            unique.append(e)
+    return unique, copies
+
+
+def chain_value(chain, values):
+    """Value of a factor chain of :func:`scaled_copies` given ``values``
+    (static DAG node -> float)."""
+    v = 1.0
+    for step in chain:
+        if step[0] == 'neg':
+            v = -v
+        elif step[0] == 'mul':
+            v *= values[step[1]]
+        else:
+            v /= values[step[1]]
+    return v
 

@@ -197,6 +197,7 @@ public:
         const int *run_start = nullptr, *run_len = nullptr;
         // entries that repeat another entry of their node's block
         const int *copy_dst = nullptr, *copy_src = nullptr;
+        const double *copy_scale = nullptr;   // null: plain copies
         int nruns = 0, V = 0, chunks = 0, ncopies = 0;
         long long P = 0, nodes = 0;
         // segmented layout: seg_dst[i*L1 + k] = seg_src[i*L0 + seg_pos[k]]
@@ -590,8 +591,12 @@ private:
                        (size_t)j.run_len[r]*sizeof(double));
                 src += j.run_len[r];
             }
-            for (int q = 0; q < j.ncopies; ++q)
-                dst[j.copy_dst[q]] = dst[j.copy_src[q]];
+            if (j.copy_scale)
+                for (int q = 0; q < j.ncopies; ++q)
+                    dst[j.copy_dst[q]] = j.copy_scale[q]*dst[j.copy_src[q]];
+            else
+                for (int q = 0; q < j.ncopies; ++q)
+                    dst[j.copy_dst[q]] = dst[j.copy_src[q]];
         }
     }
 
@@ -814,6 +819,7 @@ struct opty_hip_problem {
     // host-visible Jacobian by varying entries (opty_hip_eval_jac_persistent)
     std::vector<int> var_entries, run_start, run_len;
     std::vector<int> copy_dst, copy_src;  // opty_hip_set_entry_copies
+    std::vector<double> copy_scale;       // ..._scaled (empty: plain copies)
     int *d_var = nullptr;
     double *d_packed = nullptr, *h_packed = nullptr;
     // page-locked, device-mapped staging of the latency path (eval_mapped)
@@ -2450,6 +2456,7 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
     p->var_entries.assign(entries, entries + count);
     p->copy_dst.clear();
     p->copy_src.clear();
+    p->copy_scale.clear();
     p->run_start.clear();
     p->run_len.clear();
     for (int v = 0; v < count; ++v) {
@@ -2473,6 +2480,12 @@ int opty_hip_set_varying_entries(opty_hip_problem *p, const int32_t *entries,
 
 int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
                               const int32_t *src, int32_t count) {
+    return opty_hip_set_entry_copies_scaled(p, dst, src, nullptr, count);
+}
+
+int opty_hip_set_entry_copies_scaled(opty_hip_problem *p, const int32_t *dst,
+                                     const int32_t *src, const double *scale,
+                                     int32_t count) {
     if (!p) return fail("null handle");
     if (count < 0 || count > p->d.P) return fail("bad copy count %d", count);
     if (count > 0 && (!dst || !src)) return fail("null entries");
@@ -2491,8 +2504,14 @@ int opty_hip_set_entry_copies(opty_hip_problem *p, const int32_t *dst,
     }
     if (int rc = use_device(p)) return rc;
     HIP_TRY(hipStreamSynchronize(sync_target(p->stream)));
+    if (scale)
+        for (int k = 0; k < count; ++k)
+            if (!(scale[k] == scale[k]) || scale[k] - scale[k] != 0.0)
+                return fail("scale of copied entry %d is not finite", dst[k]);
     p->copy_dst.assign(dst, dst + count);
     p->copy_src.assign(src, src + count);
+    p->copy_scale.clear();
+    if (scale && count > 0) p->copy_scale.assign(scale, scale + count);
     p->static_valid = p->shard_valid = false;
     return 0;
 }
@@ -2564,6 +2583,9 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
             job.dense = h_blocks;
             job.copy_dst = p->copy_dst.data();
             job.copy_src = p->copy_src.data();
+    job.copy_scale = p->copy_scale.empty() ? nullptr : p->copy_scale.data();
+            job.copy_scale = p->copy_scale.empty() ? nullptr
+                                                   : p->copy_scale.data();
             job.ncopies = (int)p->copy_dst.size();
             job.chunks = 1;
             job.P = P;
@@ -2651,6 +2673,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     job.nruns = (int)p->run_start.size();
     job.copy_dst = p->copy_dst.data();
     job.copy_src = p->copy_src.data();
+    job.copy_scale = p->copy_scale.empty() ? nullptr : p->copy_scale.data();
     job.ncopies = (int)p->copy_dst.size();
     job.V = V;
     job.chunks = chunks;

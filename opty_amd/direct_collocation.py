@@ -1676,16 +1676,81 @@ class ConstraintCollocator(object):
         if self._jacobian_layout == 'coo':
             # entries that repeat another varying entry's expression are
             # filled on the host (OPTY_HOST_NO_COPIES=1: moved like the rest)
-            import os
-            unique, copies = varying_copies(self._program)
-            if os.environ.get('OPTY_HOST_NO_COPIES') == '1':
-                unique, copies = sorted(unique + [d for d, _ in copies]), []
-            hip.set_varying_entries(unique)
-            hip.set_entry_copies(copies)
+            self._install_copies(hip)
         if self.num_instance_constraints:
             idx = self.instance_constraints_free_index_map
             hip.set_instance_indices([idx[f] for f in self._inst_atoms],
                                      self._inst_rows, self._inst_cols)
+
+    def _install_copies(self, hip):
+        """Tells the handle which block entries the host path moves and which
+        it fills from another entry of the same block: exact duplicates, and
+        (r06) node-invariant multiples of a moved entry, with factors
+        evaluated here from the CURRENT known parameters / fixed interval
+        (``codegen.program.scaled_copies``; set again by :meth:`_sync_known`
+        when those change).  ``OPTY_HOST_NO_COPIES=1``: every varying entry
+        is moved; ``=exact``: exact duplicates only (A/B runs)."""
+        from .codegen.program import scaled_copies, chain_value
+        from .codegen.evaluate import evaluate_uniform
+        prog = self._program
+        mode = os.environ.get('OPTY_HOST_NO_COPIES', '')
+        unique, copies = varying_copies(prog)
+        self._copy_chains = None
+        if mode == '1':
+            hip.set_varying_entries(sorted(unique + [d for d, _ in copies]))
+            hip.set_entry_copies([])
+            return
+        if mode != 'exact':
+            u2, c2 = scaled_copies(prog)
+            scales = self._copy_scales(c2)
+            if scales is not None:
+                hip.set_varying_entries(u2)
+                hip.set_entry_copies(c2, scales)
+                self._copy_chains = c2
+                self._copy_scale_values = scales
+                return
+        hip.set_varying_entries(unique)
+        hip.set_entry_copies(copies)
+
+    def _copy_scales(self, chains):
+        """Factors of the scaled copies for the current known values, or
+        None when one of them is not a finite non-zero number (the caller
+        then moves those entries instead)."""
+        from .codegen.program import chain_value
+        from .codegen.evaluate import evaluate_uniform
+        prog = self._program
+        par, h = self._known_scalars()
+
+        def scalar(kind, idx):
+            if kind == 'par':
+                src, k = prog.pars[idx]
+                return par[k] if src == 'known' else None
+            if kind == 'h':
+                return h if prog.h[0] == 'fixed' else None
+            return None
+
+        nodes = sorted({st[1] for c in chains for ch in (c[2], c[3])
+                        for st in ch if len(st) > 1})
+        try:
+            vals = evaluate_uniform(prog.dag, nodes, scalar)
+        except (ArithmeticError, ValueError):
+            return None
+        if any(n not in vals for n in nodes):
+            return None
+        out = []
+        for dst, src, num, den in chains:
+            if num == den:
+                out.append(1.0)         # the same expression: bit for bit
+                continue
+            try:
+                d = chain_value(den, vals)
+                v = chain_value(num, vals)/d
+            except ZeroDivisionError:
+                return None
+            if not (np.isfinite(v) and np.isfinite(d) and d != 0.0):
+                return None
+            out.append(float(v))
+        return np.array(out, dtype=np.float64)
 
     @property
     def hip(self):
@@ -1720,7 +1785,13 @@ class ConstraintCollocator(object):
             if (self._uploaded_parameters is None or
                     not np.array_equal(vals, self._uploaded_parameters)):
                 hip.set_known_parameters(vals)
+                stale = self._uploaded_parameters is not None
                 self._uploaded_parameters = vals
+                if stale and hip is self._hip and \
+                        getattr(self, '_copy_chains', None):
+                    # the host path's scaled copies carry factors of the
+                    # old values
+                    self._install_copies(hip)
         if self.num_known_input_trajectories:
             if self._callable_known and free is None:
                 return

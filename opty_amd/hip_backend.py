@@ -406,6 +406,8 @@ _SIGNATURES = {
     'opty_hip_eval_instance': (ctypes.c_int, [_P, _P, _P, _P]),
     'opty_hip_set_varying_entries': (ctypes.c_int, [_P, _P, ctypes.c_int32]),
     'opty_hip_set_entry_copies': (ctypes.c_int, [_P, _P, _P, ctypes.c_int32]),
+    'opty_hip_set_entry_copies_scaled': (ctypes.c_int, [_P, _P, _P, _P,
+                                                        ctypes.c_int32]),
     'opty_hip_eval_jac_persistent': (ctypes.c_int, [_P, _P, _P,
                                                     ctypes.c_int32]),
     'opty_hip_pack_ratio': (ctypes.c_double, []),
@@ -757,13 +759,20 @@ class HipProblem(object):
         _check(self._lib.opty_hip_set_varying_entries(self._h, _ptr(e),
                                                       len(e)))
 
-    def set_entry_copies(self, copies):
+    def set_entry_copies(self, copies, scales=None):
         """``[(dst, src), ...]``: block entries filled on the host from a
-        varying entry of the same block; see ``opty_hip_set_entry_copies``."""
-        dst = np.ascontiguousarray([d for d, _ in copies], dtype=np.int32)
-        src = np.ascontiguousarray([s for _, s in copies], dtype=np.int32)
-        _check(self._lib.opty_hip_set_entry_copies(self._h, _ptr(dst),
-                                                   _ptr(src), len(dst)))
+        varying entry of the same block (``scales``: times that factor);
+        see ``opty_hip_set_entry_copies`` / ``..._scaled``."""
+        dst = np.ascontiguousarray([c[0] for c in copies], dtype=np.int32)
+        src = np.ascontiguousarray([c[1] for c in copies], dtype=np.int32)
+        if scales is None:
+            _check(self._lib.opty_hip_set_entry_copies(
+                self._h, _ptr(dst), _ptr(src), len(dst)))
+            return
+        scl = np.ascontiguousarray(scales, dtype=np.float64)
+        assert scl.shape == dst.shape
+        _check(self._lib.opty_hip_set_entry_copies_scaled(
+            self._h, _ptr(dst), _ptr(src), _ptr(scl), len(dst)))
 
     def eval_jac_persistent(self, free, jac, fresh):
         """``opty_hip_eval_jac_persistent``: host ``free``, page-locked
