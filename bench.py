@@ -476,7 +476,7 @@ def host_path(kw, dev_index, reps=15):
             ncn = col.num_collocation_nodes - 1
             pcie = {'h2d_bytes': 8*col.num_free, 'd2h_bytes': 8*moved*ncn}
         # (the host scatter verifies its thread placement over the first
-        # calls with every new vector -- opty_hip.cpp ScatterPool::feedback;
+        # calls with every new vector -- csrc/host_scatter.cpp ScatterPool::feedback;
         # they are warm-up, for each of the three collocators)
         jf = col.generate_jacobian_function()
         out['jac' + label] = med(jf, frees, warm=14)

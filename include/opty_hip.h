@@ -163,12 +163,8 @@ typedef struct opty_hip_desc {
 #define OPTY_HIP_ABI_VERSION 7
 int opty_hip_abi_version(void);
 
-/* Build verification aid: leaves `pattern` in every vector / accumulation /
- * free scalar register of every SIMD of the current device (and waits).  A
- * referee that runs it before the kernel it checks sees a kernel that reads a
- * register it never wrote -- the hipcc 7.2 faults of DESIGN.md 4.1 -- compute
- * with the pattern instead of with the previous launch's values. */
-int opty_hip_poison_registers(unsigned pattern);
+/* (The build verification's device side -- register poisoner, instruction
+ * tape -- is a library of its own: include/opty_hip_referee.h.) */
 
 /* The list schedule the library gives a persistent kernel (opty_hip_desc.
  * jac_persist / fused_persist) for a launch over `node_blocks` 64-node blocks
@@ -556,16 +552,6 @@ int opty_hip_gather_v(opty_hip_comm *c, opty_hip_problem *p,
                       const int64_t *bounds, const double *con_shard,
                       const double *jac_shard, double *con_global,
                       double *jac_global, int32_t root, int32_t what);
-
-/* Build verification (no reference counterpart: the reference trusts its C
- * compiler).  Evaluates an instruction tape of a problem's expression DAG
- * (opty_amd/codegen/tape.py: 8 int32 per instruction -- op, dst, a, b, c, d,
- * imm, 0) on `device`, one lane per node, over the HOST value table
- * vals[slot*nodes + node] (uploaded, run, downloaded in place; constant and
- * input slots pre-filled by the caller).  What the generated kernels of a code
- * object at the register limit are held to before a handle exists. */
-int opty_hip_tape_run(int32_t device, const int32_t *code, int64_t ninstr,
-                      double *vals, int64_t nslots, int64_t nodes);
 
 int opty_hip_device_count(void);
 const char *opty_hip_last_error(void);

@@ -44,7 +44,7 @@ LINE_MODE_MIN_P = 64
 #: as one contiguous span per wave (tile = 65*8 bytes per entry)
 CSR_MAX_ROW = 64
 #: bytes of one evaluation up to which the runtime's host-buffer entry points
-#: use mapped host memory (OPTY_LATENCY_PATH_BYTES in csrc/opty_hip.cpp)
+#: use mapped host memory (OPTY_LATENCY_PATH_BYTES in csrc/runtime.cpp)
 LATENCY_PATH_BYTES = 2 << 20
 
 #: node-invariant operations up to which a small problem evaluates them in
@@ -57,7 +57,7 @@ INLINE_UNIFORM_MAX_NODES = 64
 INLINE_DYNAMIC_MAX_OPS = 48
 
 #: workgroups the runtime launches opty_uni with (OPTY_UNI_WORKGROUPS in
-#: opty_hip.cpp)
+#: csrc/opty_internal.h)
 UNI_WORKGROUPS = 16
 #: waves an MI355X holds at once when a CU takes four of these kernels' waves
 #: (256 CUs x 4 SIMDs; one wave per SIMD at their register footprint)
@@ -1779,7 +1779,7 @@ class _ModuleWriter(object):
     # order == 'list': a persistent kernel.  At most RESIDENT_WAVES one-wave
     # workgroups (one per SIMD: these waves hold one alone), each evaluates
     # the list of (block, strip class) items that the runtime's list schedule
-    # gives it (``sched``, one more kernel parameter: csrc/opty_hip.cpp
+    # gives it (``sched``, one more kernel parameter: csrc/runtime.cpp
     # build_schedule) -- instead of one workgroup per item, dispatched by the
     # hardware as SIMDs fall idle.
     _LIST_HEAD = '''\

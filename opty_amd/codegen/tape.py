@@ -23,7 +23,7 @@ import numpy as np
 from . import ir
 
 TAPE_WORDS = 8
-#: opcodes shared with opty_hip.cpp (enum TapeOp)
+#: opcodes shared with csrc/referee.cpp (enum TapeOp)
 T_ADD, T_SUB, T_MUL, T_DIV, T_NEG, T_POWI, T_POW, T_MAX, T_MIN, T_ATAN2, \
     T_SELECT = range(11)
 T_UNARY0 = 16               # + index into ir.UNARY

@@ -72,24 +72,56 @@ def _hipcc():
     return exe
 
 
-def build_runtime_library(force=False):
-    """Compiles ``csrc/opty_hip.cpp`` into ``libopty_hip.so`` (in-tree)."""
-    src = os.path.join(CSRC, 'opty_hip.cpp')
-    deps = [src, os.path.join(_PKG, '..', 'include', 'opty_hip.h'),
-            os.path.join(CSRC, 'opty_poison.inc')]
-    if (not force and os.path.exists(LIB_PATH) and
-            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d)
+#: translation units of libopty_hip.so (csrc/opty_internal.h says what is
+#: where) and of the build referee's own library
+RUNTIME_SOURCES = ('runtime.cpp', 'programs.cpp', 'host_scatter.cpp',
+                   'comm.cpp')
+REFEREE_SOURCES = ('referee.cpp',)
+REFEREE_PATH = os.path.join(_PKG, 'libopty_hip_referee.so')
+
+
+def _build_shared(target, sources, extra_deps, force):
+    srcs = [os.path.join(CSRC, f) for f in sources]
+    deps = srcs + [os.path.join(_PKG, '..', 'include', 'opty_hip.h')] + [
+        os.path.join(CSRC, f) for f in extra_deps]
+    if (not force and os.path.exists(target) and
+            all(os.path.getmtime(target) >= os.path.getmtime(d)
                 for d in deps)):
-        return LIB_PATH
-    tmp = LIB_PATH + '.%d.tmp' % os.getpid()
-    cmd = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17',
-           '-Wno-unused-value', '-shared', '-fPIC', src, '-o', tmp]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
+        return target
+    tmp = target + '.%d.tmp' % os.getpid()
+    base = [_hipcc(), '--offload-arch=' + ARCH, '-O3', '-std=c++17',
+            '-Wno-unused-value', '-fPIC']
+    # one hipcc per translation unit, side by side (each takes ~20 s)
+    from concurrent.futures import ThreadPoolExecutor
+    import tempfile
+    with tempfile.TemporaryDirectory() as work:
+        objs = [os.path.join(work, os.path.basename(f) + '.o') for f in srcs]
+
+        def one(job):
+            src, obj = job
+            return subprocess.run(base + ['-c', src, '-o', obj],
+                                  capture_output=True, text=True)
+        with ThreadPoolExecutor(len(srcs)) as pool:
+            procs = list(pool.map(one, zip(srcs, objs)))
+        bad = [p for p in procs if p.returncode != 0]
+        if bad:
+            raise HipBackendError('building %s failed:\n%s' % (
+                os.path.basename(target), '\n'.join(p.stderr for p in bad)))
+        proc = subprocess.run(base + ['-shared'] + objs + ['-o', tmp],
+                              capture_output=True, text=True)
     if proc.returncode != 0:
-        raise HipBackendError('building libopty_hip.so failed:\n' +
-                              proc.stderr)
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+        raise HipBackendError('linking %s failed:\n%s' % (
+            os.path.basename(target), proc.stderr))
+    os.replace(tmp, target)
+    return target
+
+
+def build_runtime_library(force=False):
+    """Compiles ``csrc/*.cpp`` into ``libopty_hip.so`` and the build
+    referee's ``libopty_hip_referee.so`` (in-tree)."""
+    _build_shared(REFEREE_PATH, REFEREE_SOURCES, ('opty_poison.inc',), force)
+    return _build_shared(LIB_PATH, RUNTIME_SOURCES, ('opty_internal.h',),
+                         force)
 
 
 def compile_module(source, cache_dir=None, show_compile_output=False,
@@ -326,7 +358,7 @@ POISONS = (0x00000000, 0x7ff80000, 0xffffffff)
 
 def poison_registers(pattern=POISON):
     """``opty_hip_poison_registers`` on the current device."""
-    _check(load_library().opty_hip_poison_registers(pattern))
+    _check_referee(load_referee().opty_hip_poison_registers(pattern))
 
 
 def list_schedule(persist, node_blocks, class_cost):
@@ -366,7 +398,6 @@ _lib = None
 #: every symbol ``include/opty_hip.h`` declares: (restype, argtypes)
 _P = ctypes.c_void_p
 _SIGNATURES = {
-    'opty_hip_poison_registers': (ctypes.c_int, [ctypes.c_uint]),
     'opty_hip_list_schedule': (ctypes.c_int, [
         ctypes.c_int, ctypes.c_int64, ctypes.c_int,
         ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32),
@@ -442,8 +473,6 @@ _SIGNATURES = {
                                                ctypes.c_int32]),
     'opty_hip_host_alloc': (ctypes.c_void_p, [ctypes.c_size_t]),
     'opty_hip_host_free': (ctypes.c_int, [_P]),
-    'opty_hip_tape_run': (ctypes.c_int, [ctypes.c_int32, _P, ctypes.c_int64,
-                                         _P, ctypes.c_int64, ctypes.c_int64]),
     'opty_hip_device_alloc': (ctypes.c_void_p, [ctypes.c_int32,
                                                  ctypes.c_size_t]),
     'opty_hip_device_free': (ctypes.c_int, [_P]),
@@ -463,6 +492,40 @@ _SIGNATURES = {
     'opty_hip_device_count': (ctypes.c_int, []),
     'opty_hip_last_error': (ctypes.c_char_p, []),
 }
+
+
+#: entry points of libopty_hip_referee.so (include/opty_hip_referee.h)
+_REFEREE_SIGNATURES = {
+    'opty_hip_poison_registers': (ctypes.c_int, [ctypes.c_uint]),
+    'opty_hip_tape_run': (ctypes.c_int, [ctypes.c_int32, _P, ctypes.c_int64,
+                                         _P, ctypes.c_int64, ctypes.c_int64]),
+    'opty_hip_referee_last_error': (ctypes.c_char_p, []),
+}
+_referee = None
+
+
+def load_referee():
+    """Loads ``libopty_hip_referee.so`` -- the build verification's device
+    side (instruction tape, register poisoner), kept out of the runtime
+    library -- on first use."""
+    global _referee
+    if _referee is None:
+        load_library()          # one HIP runtime per process, loaded first
+        if not os.path.exists(REFEREE_PATH):
+            build_runtime_library()
+        lib = ctypes.CDLL(REFEREE_PATH)
+        for name, (res, args) in _REFEREE_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _referee = lib
+    return _referee
+
+
+def _check_referee(rc):
+    if rc != 0:
+        raise HipBackendError(
+            load_referee().opty_hip_referee_last_error().decode())
 
 
 def load_library():
@@ -521,7 +584,7 @@ def tape_run(tape, vals, device=0):
     code = np.ascontiguousarray(tape.code, dtype=np.int32)
     assert vals.dtype == np.float64 and vals.flags.c_contiguous
     assert vals.shape[0] == tape.nslots
-    _check(load_library().opty_hip_tape_run(
+    _check_referee(load_referee().opty_hip_tape_run(
         int(device), code.ctypes.data, code.shape[0], vals.ctypes.data,
         vals.shape[0], vals.shape[1]))
     return vals
@@ -846,7 +909,11 @@ class HipProblem(object):
         _check(self._lib.opty_hip_routing(
             self._h, int(nodes), ctypes.byref(cal), ctypes.byref(fl),
             ctypes.byref(jv), ms))
-        out = dict(routing='calibrated' if cal.value else 'plan',
+        banned = self.desc.get('routing', 0) & (ROUTE_NO_JAC_KERNEL |
+                                                ROUTE_NO_FUSED_KERNEL)
+        out = dict(routing='calibrated' if cal.value else (
+                       'fixed: a spilling kernel is banned' if banned
+                       else 'plan'),
                    fused_loses=bool(fl.value), jac_via_fused=bool(jv.value))
         if cal.value:
             out['ms'] = dict(opty_conjac=ms[0], opty_con=ms[1], opty_jac=ms[2])

@@ -1,5 +1,5 @@
 // Test double for librccl.so (test infrastructure): the handful of entry points
-// libopty_hip.so binds (opty_hip.cpp: load_rccl), implemented over files in
+// libopty_hip.so binds (csrc/comm.cpp: load_rccl), implemented over files in
 // /dev/shm so that SEVERAL RANKS CAN SHARE ONE GPU -- RCCL itself refuses
 // duplicate devices, and no multi-GPU box is available to the build.  It lets
 // the GPU tests drive opty_hip_bcast_free / opty_hip_gather_v with 2 and 3

@@ -231,6 +231,19 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = hb.load_library()
     for name in declared:
         assert hasattr(lib, name), name
+    # the build verification's device side is a library of its own
+    # (include/opty_hip_referee.h -> libopty_hip_referee.so): the runtime
+    # library does not carry it
+    rheader = open(os.path.join(REPO, 'include',
+                                'opty_hip_referee.h')).read()
+    rdeclared = set(re.findall(r'\b(opty_hip_[a-z_]+)\s*\(', rheader))
+    assert rdeclared == set(hb._REFEREE_SIGNATURES), \
+        rdeclared ^ set(hb._REFEREE_SIGNATURES)
+    ref = hb.load_referee()
+    for name in rdeclared:
+        assert hasattr(ref, name), name
+        if name != 'opty_hip_referee_last_error':
+            assert not hasattr(lib, name), name
     import torch
     if not torch.cuda.is_available():
         assert lib.opty_hip_device_count() == 0
