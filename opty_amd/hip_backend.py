@@ -535,10 +535,13 @@ def load_library():
         # PyTorch wheels bundle their own libamdhip64; if torch is going to
         # live in this process it must load first so that both share ONE HIP
         # runtime (two runtimes in a process see no devices).
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (OPTY_HIP_NO_TORCH=1: a torch-free process -- opty_amd.shard_host,
+        # bench.py --no-torch -- must not pay the import either)
+        if os.environ.get('OPTY_HIP_NO_TORCH') != '1':
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         if not os.path.exists(LIB_PATH):
             # not built yet (fresh checkout): build it from source with hipcc;
             # there is no CPU fallback, so a missing compiler is an error

@@ -97,7 +97,14 @@ class SharedHostVector(object):
     _mappings = 0
 
     def __init__(self, name, count, rank, group=None, owner=0, pin=True,
-                 device=None):
+                 device=None, transport=None):
+        #: ``transport``: a torch-free side channel
+        #: (``opty_amd.shard_host.SocketTransport``) instead of a
+        #: ``torch.distributed`` group -- torch is not imported then
+        if transport is not None:
+            self._init_with_transport(name, count, rank, owner, pin,
+                                      transport)
+            return
         import torch.distributed as dist
         self.count = int(count)
         # identity of THIS mapping: a later vector can be mapped at the same
@@ -170,6 +177,62 @@ class SharedHostVector(object):
                 raise error
         if rank == owner:
             os.unlink(self.path)        # the mappings keep the memory alive
+        self._pin_view = None
+        if pin:
+            from . import hip_backend as hb
+            lo, hi = (0, self.count) if pin is True else pin
+            per_page = 4096//8
+            lo = (int(lo)//per_page)*per_page
+            hi = min(self.count, -(-int(hi)//per_page)*per_page)
+            self._pin_view = self.array[lo:hi]
+            hb.host_register(self._pin_view)
+            self._pinned = True
+
+    def _create(self, name):
+        """Creates the file exclusively and maps it: ``(path, error)``."""
+        path = os.path.join('/dev/shm', '%s_%s' % (name,
+                                                   os.urandom(6).hex()))
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR |
+                         getattr(os, 'O_NOFOLLOW', 0), 0o600)
+            try:
+                os.posix_fallocate(fd, 0, max(8, 8*self.count))
+            finally:
+                os.close(fd)
+            self.array = np.memmap(path, dtype=np.float64, mode='r+',
+                                   shape=(self.count,))
+            return path, None
+        except OSError as err:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+            return path, err
+
+    def _init_with_transport(self, name, count, rank, owner, pin, transport):
+        self.count = int(count)
+        SharedHostVector._mappings += 1
+        self.token = SharedHostVector._mappings
+        self._pinned = False
+        self.array = None
+        path, error = self._create(name) if rank == owner else (None, None)
+        self.path = transport.bcast_object(path, owner)
+
+        def agree(err, what):
+            if transport.allreduce_min(0 if err else 1) == 0:
+                raise OSError('could not %s the shared host vector %s (%d '
+                              'bytes): %s' % (what, self.path, 8*self.count,
+                                              err or 'another rank failed'))
+        agree(error, 'create')
+        if rank != owner:
+            try:
+                self.array = np.memmap(self.path, dtype=np.float64,
+                                       mode='r+', shape=(self.count,))
+            except OSError as err:
+                error = err
+        agree(error, 'map')
+        if rank == owner:
+            os.unlink(self.path)
         self._pin_view = None
         if pin:
             from . import hip_backend as hb
