@@ -587,7 +587,6 @@ class _Verifier(object):
         """``con2d`` (M, b-a) / ``jac2d`` (b-a, P) tensors or arrays of the
         constraint nodes [a, b): the reference's sampled nodes among them."""
         import numpy as np
-        import torch
         nodes = self.z['nodes']
         pick = (nodes >= a) & (nodes < b)
         sel = nodes[pick] - a
@@ -595,7 +594,8 @@ class _Verifier(object):
             return
         want_j = self.z['jac_nodes'][pick]
         rowmax = np.abs(want_j.reshape(len(sel), self.M, self.C)).max(axis=2)
-        if torch.is_tensor(jac2d):
+        if not isinstance(jac2d, np.ndarray):       # device tensors
+            import torch
             idx = torch.from_numpy(sel).to(jac2d.device)
             got_j = jac2d[idx].cpu().numpy()
             got_c = con2d[:, idx].cpu().numpy()
@@ -630,6 +630,163 @@ class _Verifier(object):
         self.checked.append(label + ': checksums over all nodes')
 
 
+def main_no_torch(args):
+    """``bench.py --no-torch``: the headline step driven through ctypes
+    alone (BASELINE.json north_star: "Python host code calls, through a thin
+    ctypes C-ABI layer ...").  Same workload, same K / W / prewarm contract,
+    same JSON keys for the headline and its roofline; the secondary figures
+    are the torch line's.  N > 1: launch one process per GPU with the usual
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment (torch.distributed
+    .run exports it; no torch process group is created)."""
+    os.environ['OPTY_HIP_NO_TORCH'] = '1'
+    import numpy as np
+    from opty_amd import hip_backend as hb
+    from opty_amd.shard_host import (NodeShard, RcclTransport,
+                                     SocketTransport, launch_env)
+    from examples import problems
+    rank, world, local_rank, addr, port = launch_env()
+    assert world == max(1, args.gpus), 'one process per GPU (WORLD_SIZE)'
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+    oversub = os.environ.get('OPTY_BENCH_OVERSUBSCRIBE') == '1'
+    ndev = hb.load_library().opty_hip_device_count()
+    if oversub:
+        local_rank %= max(1, ndev)
+    side = SocketTransport(rank, world, addr, port)
+    transport = None
+    if world > 1 and not oversub:
+        transport = RcclTransport(side, device=local_rank)
+    strong = not args.weak
+    factory, fkw = problems.CONFIGS[WORKLOAD]
+    kw = factory(**dict(fkw, num_nodes=args.nodes))
+    sh = NodeShard(rank=rank if strong else 0,
+                   world_size=world if strong else 1,
+                   transport=(transport or side) if strong and world > 1
+                   else None, device=local_rank, **kw)
+    col = sh.collocator
+    hip = col.hip
+    a, b, M, P, N = sh.a, sh.b, sh.M, sh.P, sh.N
+    cnt = b - a
+    frees = [hb.DeviceVector(problems.make_free(
+        sh.num_free, seed=s + (0 if strong else 1000*rank)), local_rank)
+        for s in range(4)]
+    from opty_amd.shard_host import _device_empty
+    con, jac = _device_empty(M*cnt, local_rank), \
+        _device_empty(cnt*P, local_rank)
+    what = hb.EVAL_PAIR if args.serial else hb.EVAL_FUSED
+    lib, h = hb.load_library(), hip._h
+    fp = [f.data_ptr() for f in frees]
+    cp, jp = con.data_ptr(), jac.data_ptr()
+
+    def step(k):
+        hb._check(lib.opty_hip_eval_shard(h, what, fp[k % 4], cp, cnt, jp, a,
+                                          b))
+
+    def barrier():
+        hip.synchronize()
+        side.barrier()
+        hip.synchronize()
+
+    t_ramp = time.perf_counter()
+    k = 0
+    while (time.perf_counter() - t_ramp)*1e3 < args.prewarm_ms:
+        for _ in range(16):
+            step(k)
+            k += 1
+        hip.synchronize()
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    el = time.perf_counter() - t0
+    parts = side.gather_bytes(repr(el).encode(), 0)
+    jac_ms = hip.time_eval_shard(hb.EVAL_JAC, frees[0], None, cnt, jac, a, b,
+                                 args.steps)
+    con_ms = hip.time_eval_shard(hb.EVAL_CON, frees[1], con, cnt, None, a, b,
+                                 args.steps)
+    fused_ms = hip.time_eval_shard(hb.EVAL_FUSED, frees[2], con, cnt, jac, a,
+                                   b, args.steps)
+    # what was benched, against the reference's golden record
+    verify = {'ok': None, 'skipped': 'no reference golden for N = %d'
+              % args.nodes}
+    if args.nodes == 100000 and strong:
+        step(0)
+        hip.synchronize()
+        ver = _Verifier(M, P, N, None)
+        ver.nodes(con.numpy().reshape(M, cnt), jac.numpy().reshape(cnt, P),
+                  a, b, 'benched launch (rank %d)' % rank)
+        fails = side.gather_bytes(json.dumps(
+            [ver.failed, ver.checked, ver.worst]).encode(), 0)
+        if rank == 0:
+            got = [json.loads(f) for f in fails]
+            verify = {'ok': not any(g[0] for g in got),
+                      'worst_rel': max(g[2] for g in got), 'ranks': world,
+                      'checked': sum((g[1] for g in got), []),
+                      'failed': sum((g[0] for g in got), []),
+                      'golden': 'tests/golden/%s.npz' % WORKLOAD}
+    route = _routing(hip, cnt)
+    build = _build_check(col)
+    loaded_torch = 'torch' in sys.modules
+    side.barrier()
+    if rank == 0:
+        elapsed = max(float(p.decode()) for p in parts)
+        free_bytes = 8.0*((col.num_states +
+                           col.num_unknown_input_trajectories)*(cnt + 1))
+        if args.serial or not route['fused_pays']:
+            dom, dom_ms = 'opty_jac', jac_ms
+            dom_bytes = free_bytes + 8.0*P*cnt
+        else:
+            dom, dom_ms = 'opty_conjac', fused_ms
+            dom_bytes = free_bytes + 8.0*M*cnt + 8.0*P*cnt
+        achieved = dom_bytes/(dom_ms*1e-3)/1e9
+        kmeta = col._kernel_meta['kernels'][
+            'jac' if dom == 'opty_jac' and not route['jac_via_fused']
+            else 'conjac']
+        print(json.dumps({
+            'metric': 'constraint+Jacobian evals/sec at N=100k nodes '
+                      '(10-link pendulum on cart, backward Euler)',
+            'value': args.steps*(1 if strong else world)/elapsed,
+            'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3*elapsed/args.steps,
+            'higher_is_better': True,
+            'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {
+                'workload': '10-link inverted pendulum on cart, %d nodes, '
+                            'backward Euler, n=M=22, q=1, C=45, nnz=%d'
+                            % (N, P*(N - 1)),
+                'host': 'ctypes through include/opty_hip.h, no torch in the '
+                        'process (torch imported: %s)' % loaded_torch,
+                'step': 'constraints and Jacobian of one free vector from '
+                        'one opty_hip_eval_shard call',
+                'sharding': 'ONE problem, constraint nodes [%d, %d) of %d on '
+                            'rank 0; outputs left distributed, no data-path '
+                            'collective' % (a, b, N - 1),
+                'oversubscribed': bool(oversub),
+                'prewarm_ms': args.prewarm_ms, 'build_check': build,
+                'routing': route, 'kernel_sha': kmeta['sha'][:16],
+                'kernel_ms': {'opty_jac': jac_ms, 'opty_con': con_ms,
+                              'opty_conjac': fused_ms},
+                'nodes_per_launch': cnt, 'verify': verify},
+            'roofline': {
+                'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
+                'algorithmic_bytes_per_launch': dom_bytes,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved/HBM_PEAK_GBS,
+                'traffic': lookup_traffic(kmeta['sha'])
+                if (world == 1 and args.nodes == 100000) else None},
+        }))
+    assert not loaded_torch, 'torch was imported in --no-torch mode'
+    for v in frees + [con, jac]:
+        v.close()
+    sh.close()
+    if transport is not None:
+        transport.close()
+    side.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -656,7 +813,16 @@ def main():
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the secondary figures (serial pair, host path, '
                          'other configs, re-assembly variants)')
+    ap.add_argument('--no-torch', action='store_true',
+                    help='the same step and line from a process that never '
+                         'imports torch: device memory, launches, hipEvent '
+                         'timing and (N > 1) the RCCL communicator through '
+                         'the C ABI, rendezvous over a TCP side channel '
+                         '(opty_amd.shard_host)')
     args = ap.parse_args()
+
+    if args.no_torch:
+        return main_no_torch(args)
 
     if args.cpu_baseline_only:
         from examples import problems

@@ -1,0 +1,12 @@
+import os, sys, time
+os.environ['OPTY_HIP_TRACE']='1'
+sys.path.insert(0,'.')
+import numpy as np
+import opty_amd
+from examples import problems
+kw=problems.build('config3_10link')
+col=opty_amd.ConstraintCollocator(**kw)
+jf=col.generate_jacobian_function()
+frees=[problems.make_free(col.num_free, seed=s) for s in range(3)]
+for k in range(20):
+    t0=time.perf_counter(); jf(frees[k%3]); print('call %d %.3f ms'%(k,1e3*(time.perf_counter()-t0)), file=sys.stderr)
