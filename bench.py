@@ -1113,7 +1113,10 @@ def main():
                     'evals_per_s': args.steps/el, 'ms_per_step': 1e3*el/args.steps,
                     'what': 'eval + point-to-point gather-v of con and jac to '
                             'rank 0 (%s)' % dist.get_backend()}
-                if not oversub:
+                if not oversub or os.environ.get('OPTY_HIP_RCCL_LIBRARY'):
+                    # (oversubscribed ranks share one GPU: only with the test
+                    # transport of tests/fake_rccl in librccl's place --
+                    # tools/scale_rehearsal.sh)
                     # the same gather through the C ABI's own RCCL
                     # communicator (opty_hip_comm_create / opty_hip_gather_v:
                     # grouped ncclSend / ncclRecv issued by libopty_hip.so on

@@ -197,7 +197,18 @@ class EmitOptions(object):
                  park=0, park_live=215, park_spread=0, strips=None,
                  fused_strips=None,
                  fused_order=None, deterministic=0, class_cost=None,
-                 fused_class_cost=None):
+                 fused_class_cost=None, share_rcp=0):
+        # 1: a denominator that divides two or more values of a wave is
+        # inverted ONCE (one true division, 1.0/b) and the quotients become
+        # products with that reciprocal: an f64 division is 11-13 vector
+        # instructions (v_div_scale x2, v_rcp, Newton steps, v_div_fmas,
+        # v_div_fixup), and a wave that holds a SIMD alone pays an issue
+        # slot for every one of them (the muscle-driven leg: 78 divisions
+        # over 32 denominators; the biped 32 over 8).  A quotient then
+        # carries two roundings instead of one (a*(1/b) against a/b: <= 1.5
+        # ulp); poles and signed zeros come out as the division's.  Off by
+        # default: a launch plan turns it on where it was measured to pay
+        self.share_rcp = int(share_rcp)
         # relative wave durations of the strip classes of a persistent kernel
         # ('20.5;11.6;4.7': measured by a traced launch) for its list
         # schedule; None: the printer's estimate
@@ -427,7 +438,8 @@ class EmitOptions(object):
                  else ' fused_strips=%s' % self.fused_strips) +
                 ('' if self.fused_order is None
                  else ' fused_order=%s' % self.fused_order) +
-                (' deterministic=1' if self.deterministic else ''))
+                (' deterministic=1' if self.deterministic else '') +
+                (' share_rcp=1' if self.share_rcp else ''))
 
 
 def _lit(v):
@@ -450,8 +462,19 @@ class _Body(object):
     scope (``new_scope``), computed temporaries are emitted once.
     """
 
-    def __init__(self, dag, needed, leaf, fast_trig=True, deterministic=False):
+    def __init__(self, dag, needed, leaf, fast_trig=True, deterministic=False,
+                 share_rcp=False):
         self.dag = dag
+        # denominators that divide two or more needed values (share_rcp)
+        self.rcp = {}
+        self.shared_den = set()
+        if share_rcp:
+            count = {}
+            for i in needed:
+                if dag.op[i] == ir.DIV and dag.op[dag.args[i][1]] != ir.CONST:
+                    b = dag.args[i][1]
+                    count[b] = count.get(b, 0) + 1
+            self.shared_den = {b for b, c in count.items() if c >= 2}
         self.deterministic = bool(deterministic)
         self.trig = {0: '', 1: 'opty_', 2: 'optyu_'}[int(fast_trig)]
         self.lines = []
@@ -492,6 +515,7 @@ class _Body(object):
         again (under a new name).  Bounds the live values of a long strip at
         the price of re-evaluating what its chunks share."""
         self.done = {}
+        self.rcp = {}
         self.gen += 1
 
     def _name(self, i):
@@ -558,6 +582,14 @@ class _Body(object):
             e = '%s - %s' % (r(a[0]), r(a[1]))
         elif op == ir.MUL:
             e = '%s*%s' % (r(a[0]), r(a[1]))
+        elif op == ir.DIV and a[1] in self.shared_den:
+            inv = self.rcp.get(a[1])
+            if inv is None:
+                inv = 'r%d_%d' % (a[1], len(self.lines))
+                self.lines.append('const double %s = 1.0/%s;'
+                                  % (inv, r(a[1])))
+                self.rcp[a[1]] = inv
+            e = '%s*%s' % (r(a[0]), inv)
         elif op == ir.DIV:
             e = '%s/%s' % (r(a[0]), r(a[1]))
         elif op == ir.NEG:
@@ -1423,7 +1455,7 @@ class _ModuleWriter(object):
             return None
 
         body = _Body(d, needed, leaf, self.o.fast_trig,
-                     self.o.deterministic)
+                     self.o.deterministic, self.o.share_rcp)
         # LDS parking: the wave is planned as a whole (constraint rows
         # included) when it is worth it -- its temporaries in memory order
         # would not fit the registers

@@ -55,6 +55,9 @@ public:
         const int *copy_dst = nullptr, *copy_src = nullptr;
         const double *copy_scale = nullptr;   // null: plain copies
         int nruns = 0, V = 0, chunks = 0, ncopies = 0;
+        // chunk c covers the nodes [chunk_bounds[c], chunk_bounds[c + 1]);
+        // null: `chunks` equal parts of `nodes`
+        const long long *chunk_bounds = nullptr;
         long long P = 0, nodes = 0;
         // segmented layout: seg_dst[i*L1 + k] = seg_src[i*L0 + seg_pos[k]]
         // (the repeated entries, filled from the varying entries that have
@@ -501,8 +504,10 @@ private:
                     else std::this_thread::sleep_for(
                         std::chrono::microseconds(20));
                 }
-                const long long a = j.nodes*c/j.chunks,
-                                b = j.nodes*(c + 1)/j.chunks;
+                const long long a = j.chunk_bounds ? j.chunk_bounds[c]
+                                                   : j.nodes*c/j.chunks,
+                                b = j.chunk_bounds ? j.chunk_bounds[c + 1]
+                                                   : j.nodes*(c + 1)/j.chunks;
                 if (j.rows_dst) {
                     const long long c0 = j.bounds[c], c1 = j.bounds[c + 1];
                     const long long s0 = c0 + (c1 - c0)*t/T,
@@ -546,8 +551,10 @@ private:
                 bool helped = false;
                 const unsigned now = now_us();
                 for (int c = 0; c < j.chunks; ++c) {
-                    const long long a = j.nodes*c/j.chunks,
-                                    b = j.nodes*(c + 1)/j.chunks;
+                    const long long a = j.chunk_bounds
+                        ? j.chunk_bounds[c] : j.nodes*c/j.chunks,
+                                    b = j.chunk_bounds
+                        ? j.chunk_bounds[c + 1] : j.nodes*(c + 1)/j.chunks;
                     for (int k = 0; k < slices_; ++k) {
                         const unsigned at = slice_state_[c*MAX_SLICES + k].v
                             .load(std::memory_order_relaxed);
@@ -906,6 +913,35 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     int chunks = (int)std::max<size_t>(1, std::min<size_t>(
         32, packed*sizeof(double)/(16u << 20)));
     chunks = (int)std::min<long long>(chunks, count);
+    // r06 (profiles/r06_host_path.txt): the host scatter runs right behind
+    // the DMA engine (it moves a chunk barely faster than the link delivers
+    // one), so a call ends one chunk's scatter after the last byte has
+    // landed -- 0.26 ms for a 18 MB chunk.  The LAST chunks are therefore
+    // halved twice (.. 1, 1, 1/2, 1/4, 1/4 of a regular one): the tail
+    // shrinks to a quarter chunk's scatter at the price of two more copies.
+    // OPTY_HIP_HOST_TAPER=0 keeps equal chunks.
+    static const bool taper = [] {
+        const char *v = getenv("OPTY_HIP_HOST_TAPER");
+        return !(v && v[0] == '0');
+    }();
+    // chunk c covers the nodes [bound(c), bound(c + 1)); kept in the handle:
+    // the scatter workers read it (nobody does right now: quiesce() above)
+    std::vector<long long> &bound = p->chunk_bounds;
+    bound.clear();
+    {
+        const bool tp = taper && chunks >= 4 &&
+                        chunks + 2 <= ScatterPool::MAX_CHUNKS && produce;
+        for (int c = 0; c <= chunks; ++c)
+            bound.push_back(count*c/chunks);
+        if (tp) {
+            const long long a = bound[(size_t)chunks - 1], b = count;
+            bound.pop_back();
+            bound.push_back(a + (b - a)/2);
+            bound.push_back(a + (b - a)*3/4);
+            bound.push_back(b);
+            chunks += 2;
+        }
+    }
     // windows (see `produce`); never on the legacy stream: an event
     // recorded there and waited for on another stream crashed inside the
     // runtime (ROCm 7.0.2)
@@ -920,10 +956,23 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         p->chunk_events.push_back(e);
     }
-    if (W > 1 && !p->copy_stream)
+    if (W > 1 && !p->copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream,
                                          hipStreamNonBlocking));
-    hipStream_t out = W > 1 ? p->copy_stream : p->stream;
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream2,
+                                         hipStreamNonBlocking));
+    }
+    // the chunks alternate between two copy streams (r06): the engine's gap
+    // between two consecutive copies of ONE stream (~25 us each, 0.3 ms over
+    // the twelve chunks of config 3: 53 GB/s against the link's 56) is filled
+    // by the other stream's copy.  OPTY_HIP_COPY_STREAMS=1: one stream.
+    static const bool two = [] {
+        const char *v = getenv("OPTY_HIP_COPY_STREAMS");
+        return !(v && v[0] == '1');
+    }();
+    hipStream_t outs[2] = {W > 1 ? p->copy_stream : p->stream,
+                           W > 1 && two ? p->copy_stream2
+                                        : (W > 1 ? p->copy_stream : p->stream)};
     int next_chunk = 0;
     for (int w = 0; w < W; ++w) {
         const long long wa = count*w/W, wb = count*(w + 1)/W;
@@ -940,12 +989,14 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         if (W > 1) {
             hipEvent_t ready = p->chunk_events[(size_t)chunks + (size_t)w];
             HIP_TRY(hipEventRecord(ready, p->stream));
-            HIP_TRY(hipStreamWaitEvent(out, ready, 0));
+            HIP_TRY(hipStreamWaitEvent(outs[0], ready, 0));
+            if (outs[1] != outs[0])
+                HIP_TRY(hipStreamWaitEvent(outs[1], ready, 0));
         }
-        while (next_chunk < chunks &&
-               count*(next_chunk + 1)/chunks <= wb) {
-            const long long a = count*next_chunk/chunks,
-                            b = count*(next_chunk + 1)/chunks;
+        while (next_chunk < chunks && bound[(size_t)next_chunk + 1] <= wb) {
+            const long long a = bound[(size_t)next_chunk],
+                            b = bound[(size_t)next_chunk + 1];
+            hipStream_t out = outs[next_chunk & 1];
             HIP_TRY(hipMemcpyAsync(p->h_packed + a*V, p->d_packed + a*V,
                                    (size_t)(b - a)*V*sizeof(double),
                                    hipMemcpyDeviceToHost, out));
@@ -967,6 +1018,7 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     job.ncopies = (int)p->copy_dst.size();
     job.V = V;
     job.chunks = chunks;
+    job.chunk_bounds = bound.data();
     job.P = P;
     job.nodes = count;
     // OPTY_HIP_TRACE=1: where the time of one call goes (stderr)

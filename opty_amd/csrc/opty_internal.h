@@ -106,6 +106,7 @@ struct opty_hip_problem {
                   k_inst = nullptr, k_uni = nullptr;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t copy_stream = nullptr;  // device-to-host side of a pipeline
+    hipStream_t copy_stream2 = nullptr; // ... its chunks alternate between two
     double *d_params = nullptr, *d_known = nullptr, *d_uni = nullptr;
     bool uni_dirty = true;   // node-invariant table needs (re)computing
     long long *d_inst_idx = nullptr, *d_inst_rows = nullptr,
@@ -138,6 +139,7 @@ struct opty_hip_problem {
     double *d_dense = nullptr;   // node-major blocks the kernels write
     double *d_seg = nullptr;     // the same values in segmented order
     std::vector<hipEvent_t> chunk_events;
+    std::vector<long long> chunk_bounds;  // node ranges of the DMA chunks
     size_t packed_cap = 0;                // doubles in d_packed / h_packed
     const double *static_host = nullptr;  // vector whose invariant entries
     bool static_valid = false;            // ... are up to date

@@ -873,6 +873,7 @@ int opty_hip_destroy(opty_hip_problem *p) {
     if (p->ev_cal1) (void)hipEventDestroy(p->ev_cal1);
     if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
+    if (p->copy_stream2) (void)hipStreamDestroy(p->copy_stream2);
     if (p->module) (void)hipModuleUnload(p->module);
     delete p;
     return 0;

@@ -48,7 +48,7 @@ def test_handle_calibrates_its_routing_on_first_use(monkeypatch):
     if after['jac_via_fused']:
         assert ms['opty_conjac'] <= ms['opty_jac']*1.0001
     # other launch sizes are measured on their own
-    assert hip.routing(nodes=7)['routing'] == 'plan'
+    assert hip.routing(nodes=100000)['routing'] == 'plan'
     jac2 = np.empty_like(jac0)
     hip.eval_jac(free, jac2, hb.HOST)
     for got, want in ((con, con0), (jac, jac0), (jac2, jac0)):
@@ -77,7 +77,7 @@ def test_banned_kernel_is_never_launched(banned, monkeypatch, tmp_path):
                                         verify_builds='off', **kw)
     source, meta = col.generate_source()
     # body of the banned kernel -> nothing
-    m = re.search(r'void\s+%s\s*\([^)]*\)\s*\{' % banned, source)
+    m = re.search(r'^%s\s*\([^)]*\)\s*\{' % banned, source, re.M)
     assert m, 'kernel not found in the printed module'
     depth, k = 1, m.end()
     while depth:

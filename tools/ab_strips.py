@@ -44,9 +44,10 @@ def main():
         special = 'specialize' in spec
         determ = '+deterministic' in spec
         uniform = '+uniform_trig' in spec
+        rcp = '+share_rcp' in spec
         bare = spec.replace('+specialize', '').replace(',specialize=1', '') \
             .replace('specialize=1', '').replace('+deterministic', '') \
-            .replace('+uniform_trig', '')
+            .replace('+uniform_trig', '').replace('+share_rcp', '')
         opts = None if bare in ('auto', '') else (
             EmitOptions() if bare == 'default' else parse(bare))
         if uniform:
@@ -58,6 +59,14 @@ def main():
                     specialize_parameters=special, **kw)._printer_options()
             opts = copy.copy(opts)
             opts.fast_trig = 2
+        if rcp:
+            # ... with shared reciprocals (EmitOptions.share_rcp)
+            import copy
+            if opts is None:
+                opts = opty_amd.ConstraintCollocator(
+                    specialize_parameters=special, **kw)._printer_options()
+            opts = copy.copy(opts)
+            opts.share_rcp = 1
         col = opty_amd.ConstraintCollocator(
             emit_options=opts, specialize_parameters=special,
             deterministic=determ, **kw)
