@@ -197,7 +197,21 @@ class EmitOptions(object):
                  park=0, park_live=215, park_spread=0, strips=None,
                  fused_strips=None,
                  fused_order=None, deterministic=0, class_cost=None,
-                 fused_class_cost=None, share_rcp=0):
+                 fused_class_cost=None, share_rcp=0, publish=0):
+        # 1 (r06, launches that under-fill the chip -- node shards): the
+        # waves of a block form ONE workgroup and evaluate the block's
+        # isomorphic sub-models (codegen/isomorph.py: the musculotendon
+        # actuators and activation dynamics of the muscle-driven leg) ONCE,
+        # side by side -- one instance per wave, longest first -- before
+        # their strips: every instance's interface values (the few values
+        # the rest of the block reads: 13 per muscle) are published in LDS
+        # rows behind the ring tiles, one barrier later every strip reads
+        # them as it reads the input slab.  The heavy strips lose the work
+        # they used to repeat (leg: 3465 / 3363 -> 1900 / 1798 weighted
+        # operations after a 496-operation stage).  Costs LDS (82 rows for
+        # the leg) and a workgroup as wide as the block has waves: only
+        # where a CU holds one block anyway
+        self.publish = int(publish)
         # 1: a denominator that divides two or more values of a wave is
         # inverted ONCE (one true division, 1.0/b) and the quotients become
         # products with that reciprocal: an f64 division is 11-13 vector
@@ -439,7 +453,8 @@ class EmitOptions(object):
                 ('' if self.fused_order is None
                  else ' fused_order=%s' % self.fused_order) +
                 (' deterministic=1' if self.deterministic else '') +
-                (' share_rcp=1' if self.share_rcp else ''))
+                (' share_rcp=1' if self.share_rcp else '') +
+                (' publish=1' if self.publish else ''))
 
 
 def _lit(v):
@@ -971,6 +986,8 @@ class _ModuleWriter(object):
         self._con_nt = False        # constraint stores of the kernel in print
         self._park_rows = 0         # LDS rows the planned waves park values in
         self._plans = []
+        self._pub = None            # publication plan (EmitOptions.publish)
+        self._pub_rows = {}         # published node -> LDS row, kernel in print
 
     # -- leaves -------------------------------------------------------------
     def _is_vec_input(self, i):
@@ -1386,11 +1403,108 @@ class _ModuleWriter(object):
             self.group_ranges()
         return self._auto
 
+    # -- publication of isomorphic sub-models (EmitOptions.publish) -----------
+    def _publication(self):
+        """``(rows, tasks)``: ``rows`` = {published node: LDS row}, ``tasks``
+        = [(interface nodes of one instance, its weight)], from the
+        isomorphic instance groups of the block (``codegen/isomorph.py``);
+        None when there is nothing worth a barrier."""
+        if self._pub is None:
+            from . import isomorph
+            d, p = self.dag, self.p
+            is_leaf = isomorph.default_leaf(d)
+            roots = list(p.con_out) + list(p.jac_out)
+            need = set(i for i in d.reachable(roots) if not is_leaf(i))
+            users = {}
+            for i in need:
+                for j in d.operands(i):
+                    if j in need:
+                        users.setdefault(j, []).append(i)
+            outs = set(roots)
+            rows, tasks = {}, []
+            for g in isomorph.instance_groups(
+                    d, roots, lambda i: _node_weight(d, i), is_leaf):
+                for r in g['roots']:
+                    c = isomorph.cone(d, r, is_leaf)
+                    iface = sorted(v for v in c if v in outs or any(
+                        u not in c for u in users.get(v, ())))
+                    for v in iface:
+                        rows.setdefault(v, len(rows))
+                    tasks.append((iface, g['weight']))
+            self._pub = (rows, tasks) if tasks else False
+        return self._pub or None
+
+    def _publish_stage(self, W, slab_of):
+        """Code of the stage between the slab fill and the strips: wave ``w``
+        of the workgroup evaluates its share of the instances (longest
+        first onto the least loaded wave) and stores their interface values
+        into the ``pub`` rows; one barrier."""
+        rows, tasks = self._publication()
+        d = self.dag
+        loads, mine = [0]*W, [[] for _ in range(W)]
+        for iface, weight in sorted(tasks, key=lambda t: -t[1]):
+            w = loads.index(min(loads))
+            loads[w] += weight
+            mine[w].append(iface)
+        leaf = self._leaf_fn(slab_of, {})
+        lines = ['switch (wave) {']
+        stored = set()
+        for w in range(W):
+            if not mine[w]:
+                continue
+            need = set(d.reachable([v for iface in mine[w] for v in iface]))
+            body = _Body(d, need, leaf, self.o.fast_trig,
+                         self.o.deterministic, self.o.share_rcp)
+            for iface in mine[w]:
+                body.new_scope()
+                for v in iface:
+                    ref = body.emit(v)
+                    if v not in stored:
+                        stored.add(v)
+                        body.lines.append('pub[%d + lane] = %s;'
+                                          % (rows[v]*TS, ref))
+            body.end_scope()
+            lines.append('case %d: {' % w)
+            lines += ['    ' + ln for ln in body.lines]
+            lines.append('} break;')
+        lines += ['default: break;', '}', '__syncthreads();']
+        return lines, max(loads)
+
+    def _leaf_fn(self, slab_of, published):
+        """``leaf(i)`` of a wave's straight-line code: how a value that is
+        fetched rather than computed is fetched (input slab, node-invariant
+        table / literal / scalar home, published row), or None."""
+        p, d = self.p, self.dag
+
+        def leaf(i):
+            if i in published:
+                return 'pub[%d + lane]' % (published[i]*TS)
+            if self._is_vec_input(i):
+                kind, r = d.args[i]
+                off = p.cur_offset if kind == 'cur' else p.adj_offset
+                return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
+            if self._uniform_leaf(i):
+                if i in self.literals:
+                    return _lit(self.literals[i])
+                if self.inline_uni or (self.inline_dynamic and
+                                       self._dynamic(i)):
+                    return self._scalar_source(i)
+                # diagnostics (wrong values): what would the kernel cost if
+                # node-invariant operands were literals / free?
+                if self.o.ablate == 'uni_lit':
+                    return _lit(1.0 + 1.0/(3.0 + self._slot(i)))
+                if self.o.ablate == 'uni_free':
+                    self._slot(i)
+                    return 'h'
+                return 'uni_c[%d]' % self._slot(i)
+            return None
+        return leaf
+
     # -- kernels ---------------------------------------------------------------
     def _kernel_rows(self, groups, con_of_group):
         """Trajectory rows any wave of the kernel reads (the shared slab)."""
         p, d = self.p, self.dag
-        roots = []
+        roots = list(self._pub_rows)
         for grp, cons in zip(groups, con_of_group):
             for e0, e1 in grp:
                 vend = self._virtual_end(e1) if e1 > e0 else e1
@@ -1433,26 +1547,7 @@ class _ModuleWriter(object):
         needed = set(d.reachable(roots))
         R = K + 16
 
-        def leaf(i):
-            if self._is_vec_input(i):
-                kind, r = d.args[i]
-                off = p.cur_offset if kind == 'cur' else p.adj_offset
-                return 'lds[%d + lane + %d]' % (slab_of[r]*TS, off)
-            if self._uniform_leaf(i):
-                if i in self.literals:
-                    return _lit(self.literals[i])
-                if self.inline_uni or (self.inline_dynamic and
-                                       self._dynamic(i)):
-                    return self._scalar_source(i)
-                # diagnostics (wrong values): what would the kernel cost if
-                # node-invariant operands were literals / free?
-                if self.o.ablate == 'uni_lit':
-                    return _lit(1.0 + 1.0/(3.0 + self._slot(i)))
-                if self.o.ablate == 'uni_free':
-                    self._slot(i)
-                    return 'h'
-                return 'uni_c[%d]' % self._slot(i)
-            return None
+        leaf = self._leaf_fn(slab_of, self._pub_rows)
 
         body = _Body(d, needed, leaf, self.o.fast_trig,
                      self.o.deterministic, self.o.share_rcp)
@@ -1904,10 +1999,32 @@ class _ModuleWriter(object):
                      <= 16 and not con_of_group[g]
                      for g, grp in enumerate(groups)]
             keep = [c == (self.o.ablate == 'only_cheap') for c in cheap]
+        # publication of the block's isomorphic sub-models (one workgroup
+        # per block, a stage and a barrier before the strips): Jacobian
+        # kernels of line-mode blocks with several waves, hardware dispatch
+        self._pub_rows = {}
+        pub = None
+        if self.o.publish and name in ('opty_jac', 'opty_conjac') and \
+                G > 1 and G <= 16 and self.line_mode() and \
+                (order or self.o.order) != 'list' and not self.o.park and \
+                self.o.ablate is None and not self.o.trace:
+            pub = self._publication()
+        if pub is not None:
+            self._pub_rows = pub[0]
         rows = self._kernel_rows([g for g, k in zip(groups, keep) if k],
                                  [c for c, k in zip(con_of_group, keep) if k])
-        slab_of = {r: k for k, r in enumerate(rows)}
         ring_rows = max([self._ring_rows(g) for g in groups] + [0])
+        if pub is not None:
+            nring = sum(any(e1 > e0 for e0, e1 in grp) for grp in groups)
+            if (len(rows) + nring*ring_rows + len(pub[0]))*TS*8 > 160*1024:
+                # does not fit a CU's LDS next to the ring tiles
+                pub, self._pub_rows = None, {}
+                rows = self._kernel_rows(
+                    [g for g, k in zip(groups, keep) if k],
+                    [c for c, k in zip(con_of_group, keep) if k])
+            else:
+                W = G
+        slab_of = {r: k for k, r in enumerate(rows)}
         if W is None:
             if G <= 4 and any(con_of_group) and not self.o.strips and \
                     not self.o.fused_strips and \
@@ -1953,7 +2070,8 @@ class _ModuleWriter(object):
             rings = max(rings, sum(mine))
         if W == 1:
             rings = 1           # one size per kernel: nothing to share
-        lds_doubles = max(1, (len(rows) + rings*ring_rows)*TS +
+        pub_base = (len(rows) + rings*ring_rows)*TS
+        lds_doubles = max(1, pub_base + len(self._pub_rows)*TS +
                           W*park_rows*WAVE)
         occ = ' __attribute__((amdgpu_waves_per_eu(%d, %d)))' % (
             self.o.occupancy, self.o.occupancy) if self.o.occupancy else ''
@@ -2044,6 +2162,12 @@ class _ModuleWriter(object):
             '__builtin_amdgcn_s_getreg(GETREG_IMMED(15, 0, 4));',
             '    }'] if self.o.trace else []
         fill = ['    ' + ln for ln in self._slab_fill(rows, slab_of, W)]
+        stage_weight = 0
+        if pub is not None:
+            assert W == G and not listed and not park_rows
+            stage, stage_weight = self._publish_stage(W, slab_of)
+            fill += ['    double *const pub = lds + %d;' % pub_base] + \
+                ['    ' + ln for ln in stage]
         if listed:
             # one loop around the switch: items in the order of the schedule
             src += [self._LIST_LOOP,
@@ -2083,6 +2207,8 @@ class _ModuleWriter(object):
         return text, dict(name=name, groups=G, waves_per_wg=W,
                           wgs_per_block=sets, lds_bytes=lds_doubles*8,
                           park_rows=park_rows,
+                          published_rows=len(self._pub_rows),
+                          publish_stage_weight=stage_weight,
                           persist=RESIDENT_WAVES if listed else 0,
                           class_cost=self._given_cost(name, G) or [
                               float(sum(self._weighted_cost(e0, e1) +

@@ -374,14 +374,19 @@ public:
     // wakes up later and writes the same values once more; quiesce() keeps
     // the next job (and the next DMA into the staging buffer it reads) behind
     // it.
+    // r06: ... and then for every worker to have left the job
+    // all the same.  A straggler that still wrote into the caller's vector
+    // after the API call had returned was a use-after-free in waiting (the
+    // reference-shaped callbacks hand back FRESH arrays, which the caller
+    // may free at once); what the slices still buy is that the straggler's
+    // remaining slice is at most one, not its whole share.
     void wait() {
         if (sliced_) {
             const int total = job_.chunks*slices_;
             while (slices_done_.load(std::memory_order_acquire) < total)
                 std::this_thread::yield();
-        } else {
-            quiesce();
         }
+        quiesce();
         busy_.unlock();
     }
     // every worker has left the last job
