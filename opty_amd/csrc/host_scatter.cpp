@@ -929,6 +929,15 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         const char *v = getenv("OPTY_HIP_HOST_TAPER");
         return !(v && v[0] == '0');
     }();
+    // windows (see `produce`); never on the legacy stream: an event
+    // recorded there and waited for on another stream crashed inside the
+    // runtime (ROCm 7.0.2)
+    int W = 1;
+    if (produce) {
+        W = windows > 0 ? windows
+                        : host_windows(p, packed*sizeof(double), count);
+        chunks = std::max(chunks, W);
+    }
     // chunk c covers the nodes [bound(c), bound(c + 1)); kept in the handle:
     // the scatter workers read it (nobody does right now: quiesce() above)
     std::vector<long long> &bound = p->chunk_bounds;
@@ -946,15 +955,6 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
             bound.push_back(b);
             chunks += 2;
         }
-    }
-    // windows (see `produce`); never on the legacy stream: an event
-    // recorded there and waited for on another stream crashed inside the
-    // runtime (ROCm 7.0.2)
-    int W = 1;
-    if (produce) {
-        W = windows > 0 ? windows
-                        : host_windows(p, packed*sizeof(double), count);
-        chunks = std::max(chunks, W);
     }
     while ((int)p->chunk_events.size() < chunks + W) {
         hipEvent_t e;
