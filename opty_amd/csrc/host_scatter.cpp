@@ -918,16 +918,17 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
     int chunks = (int)std::max<size_t>(1, std::min<size_t>(
         32, packed*sizeof(double)/(16u << 20)));
     chunks = (int)std::min<long long>(chunks, count);
-    // r06 (profiles/r06_host_path.txt): the host scatter runs right behind
-    // the DMA engine (it moves a chunk barely faster than the link delivers
-    // one), so a call ends one chunk's scatter after the last byte has
-    // landed -- 0.26 ms for a 18 MB chunk.  The LAST chunks are therefore
-    // halved twice (.. 1, 1, 1/2, 1/4, 1/4 of a regular one): the tail
-    // shrinks to a quarter chunk's scatter at the price of two more copies.
-    // OPTY_HIP_HOST_TAPER=0 keeps equal chunks.
+    // r06 A/B (profiles/r06_host_path.txt), both OFF by default because
+    // neither paid: (i) tapering the LAST chunks (.. 1, 1, 1/2, 1/4, 1/4 of
+    // a regular one: OPTY_HIP_HOST_TAPER=1) does not shorten the 0.26 ms
+    // between the last byte and the last scattered value -- that lag is the
+    // host threads running a constant distance behind the DMA engine, not
+    // the last chunk's own scatter; (ii) two copy streams
+    // (OPTY_HIP_COPY_STREAMS=2, below) share the link instead of filling
+    // each other's gaps: the download takes 4.5 ms instead of 3.7.
     static const bool taper = [] {
         const char *v = getenv("OPTY_HIP_HOST_TAPER");
-        return !(v && v[0] == '0');
+        return v && v[0] == '1';
     }();
     // windows (see `produce`); never on the legacy stream: an event
     // recorded there and waited for on another stream crashed inside the
@@ -967,13 +968,11 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
         HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream2,
                                          hipStreamNonBlocking));
     }
-    // the chunks alternate between two copy streams (r06): the engine's gap
-    // between two consecutive copies of ONE stream (~25 us each, 0.3 ms over
-    // the twelve chunks of config 3: 53 GB/s against the link's 56) is filled
-    // by the other stream's copy.  OPTY_HIP_COPY_STREAMS=1: one stream.
+    // OPTY_HIP_COPY_STREAMS=2: the chunks alternate between two copy
+    // streams (measured slower, see above)
     static const bool two = [] {
         const char *v = getenv("OPTY_HIP_COPY_STREAMS");
-        return !(v && v[0] == '1');
+        return v && v[0] == '2';
     }();
     hipStream_t outs[2] = {W > 1 ? p->copy_stream : p->stream,
                            W > 1 && two ? p->copy_stream2
