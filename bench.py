@@ -351,6 +351,12 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
         # (every launch of this entry reads ONE free vector; the headline
         # rotates four -- 1-2 % of the bytes of a write stream)
         free_vectors=1,
+        # (True: the generic module of this problem spills hundreds of scalar
+        # registers, so the collocator printed its known parameters into
+        # the kernels as literals on its own -- the default since r06,
+        # ConstraintCollocator(specialize_parameters=None); rebuilt when the
+        # known parameter map changes)
+        auto_specialised=bool(col._auto_specialized),
         build_check=_build_check(col), **route)
     if name in SPECIALISED_ENTRIES:
         # opt-in: node-invariant values as literals of the kernels

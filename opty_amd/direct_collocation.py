@@ -80,8 +80,8 @@ class ConstraintCollocator(object):
                  emit_options=None, prune_zeros=False,
                  jacobian_layout='coo', launch_nodes=None,
                  deterministic=False, verify_builds=None,
-                 specialize_parameters=False):
-        # opt-in: the node-invariant sub-expressions (products of masses and
+                 specialize_parameters=None):
+        # True: the node-invariant sub-expressions (products of masses and
         # lengths, 1/h ...) are printed into the kernels as float64 literals,
         # computed on the host from the known parameter values and the fixed
         # node time interval at build time, instead of being read from the
@@ -92,7 +92,22 @@ class ConstraintCollocator(object):
         # re-read on every call, as in the reference) the kernels are printed
         # and compiled again -- seconds, not microseconds: for solves with
         # fixed parameters.
-        self._specialize = bool(specialize_parameters)
+        # None (the default since r06) = automatic: the generic module is
+        # built first; when its fused kernel spills at least
+        # ``_AUTO_SPECIALIZE_SGPR_SPILLS`` scalar registers into vector lanes
+        # -- the class that gains (the muscle-driven leg: 255-377 spilled
+        # SGPRs, -7 ... -13 %; the 24-link stand-ins -3 %; the biped, 58
+        # spilled, is no faster) -- and there are known parameters to print,
+        # the specialised module takes its place.  A caller whose known
+        # parameters keep changing (two rebuilds) is moved back to the
+        # generic module for good.  False: never.
+        if specialize_parameters not in (None, True, False):
+            raise ValueError('specialize_parameters must be None, True or '
+                             'False.')
+        self._specialize_mode = specialize_parameters
+        self._specialize = specialize_parameters is True
+        self._auto_specialized = False
+        self._respecializations = 0
         self._specialized_for = None
         self._literal_values = None
         # how builds are held to the expression DAG before their first use
@@ -670,6 +685,19 @@ class ConstraintCollocator(object):
         import copy
         from . import isa_check
         hsaco, meta = self._build_spill_free(opt_level)
+        if self._wants_auto_specialization(hsaco, opt_level):
+            # the generic module of this problem is of the class that gains
+            # from literals: build (and from here on use) the specialised one
+            logger.info('the generic kernels spill %d scalar registers: '
+                        'using parameter-specialised kernels '
+                        '(specialize_parameters=None: automatic)',
+                        hb.cached_kernel_resources(hsaco)['opty_conjac'][
+                            '.sgpr_spill_count'])
+            self._specialize = self._auto_specialized = True
+            self._specialized_for = self._literal_values = None
+            hsaco, meta = self._build_spill_free(opt_level)
+        if self._auto_specialized:
+            meta = dict(meta, auto_specialized=True)
         banned = set(meta.get('banned_kernels', ()))
         names = [k for k in ('opty_con', 'opty_jac', 'opty_conjac')
                  if k not in banned]
@@ -704,6 +732,26 @@ class ConstraintCollocator(object):
                 if k in meta}
         return twin, dict(tmeta, isa_exec_copies={}, isa_replaced=dict(hits),
                           **keep)
+
+    #: spilled scalar registers of the generic fused kernel from which the
+    #: parameter-specialised module is used automatically
+    _AUTO_SPECIALIZE_SGPR_SPILLS = 200
+
+    def _wants_auto_specialization(self, hsaco, opt_level):
+        if self._specialize_mode is not None or self._specialize or \
+                self._auto_specialized is None or opt_level is not None or \
+                self._emit_options is not None or self._deterministic or \
+                not (self.num_known_parameters or
+                     not self._variable_duration):
+            return False
+        if self._pinned_build() is not None:
+            return False
+        try:
+            res = hb.cached_kernel_resources(hsaco)
+            spilled = res['opty_conjac']['.sgpr_spill_count']
+        except (KeyError, hb.HipBackendError):
+            return False
+        return spilled >= self._AUTO_SPECIALIZE_SGPR_SPILLS
 
     def _build_spill_free(self, opt_level=None):
         """Emits and compiles this problem's module; returns ``(hsaco path,
@@ -1776,8 +1824,19 @@ class ConstraintCollocator(object):
             # the kernels carry the OLD values as literals: print, compile
             # and verify them again for the new ones, inside the same handle
             # object (closures hold on to it)
-            logger.warning('known parameters changed: rebuilding the '
-                           'parameter-specialised kernels')
+            self._respecializations += 1
+            if self._auto_specialized and self._respecializations >= 2:
+                # automatic specialisation is for solves with FIXED
+                # parameters: this caller's keep changing
+                logger.warning('known parameters changed again: back to the '
+                               'generic kernels (specialize_parameters=True '
+                               'keeps rebuilding instead)')
+                self._specialize = False
+                self._auto_specialized = None      # never again
+                self._literal_values = self._specialized_for = None
+            else:
+                logger.warning('known parameters changed: rebuilding the '
+                               'parameter-specialised kernels')
             self._respecialize(hip)
         if self.num_known_parameters:
             vals = np.array([float(self.known_parameter_map[p])
@@ -2137,7 +2196,7 @@ class Problem(object):
                  bounds=None, show_compile_output=False, backend='hip',
                  eom_bounds=None, device=0, prune_zeros=False,
                  jacobian_layout='coo', deterministic=False,
-                 verify_builds=None, specialize_parameters=False):
+                 verify_builds=None, specialize_parameters=None):
         if not sm.Matrix(equations_of_motion).has(sm.Derivative):
             raise ValueError('No time derivatives are present. The equations '
                              'of motion must be ordinary differential '

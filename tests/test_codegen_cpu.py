@@ -1095,3 +1095,38 @@ def test_printer_expansions_against_sympy():
     from opty_amd.codegen.lower import LoweringError
     with pytest.raises(LoweringError):
         low.lower(sm.Function('mystery')(a))
+
+
+def test_automatic_parameter_specialisation_follows_the_scalar_spills():
+    """``specialize_parameters=None`` (the default): a problem whose generic
+    fused kernel spills hundreds of scalar registers into vector lanes -- the
+    muscle-driven leg -- gets its known parameters printed as literals
+    without being asked; a small problem, a caller who said ``False``, a
+    ``deterministic`` build and a caller who fixed the printer options keep
+    the generic module."""
+    kw = problems.build('one_legged_small')
+    col = ConstraintCollocator(**kw)
+    hsaco, meta = col.prebuild()
+    assert col._auto_specialized is True and meta['auto_specialized']
+    assert col._specialize and col._literal_values
+    assert 'uni_c[' not in col._built_source.split('opty_conjac')[1][:200000]
+    spilled = hb.cached_kernel_resources(hsaco)['opty_conjac'][
+        '.sgpr_spill_count']
+    assert spilled < ConstraintCollocator._AUTO_SPECIALIZE_SGPR_SPILLS
+    never = ConstraintCollocator(specialize_parameters=False, **kw)
+    h2, m2 = never.prebuild()
+    assert not never._specialize and not m2.get('auto_specialized')
+    assert hb.cached_kernel_resources(h2)['opty_conjac'][
+        '.sgpr_spill_count'] >= ConstraintCollocator._AUTO_SPECIALIZE_SGPR_SPILLS
+    assert h2 != hsaco
+    det = ConstraintCollocator(deterministic=True, **kw)
+    det.prebuild()
+    assert not det._specialize
+    fixed = ConstraintCollocator(emit_options=never._built_options, **kw)
+    fixed.prebuild()
+    assert not fixed._specialize
+    small = ConstraintCollocator(**problems.build('msd_be_small'))
+    small.prebuild()
+    assert not small._specialize and small._auto_specialized is False
+    with pytest.raises(ValueError, match='specialize_parameters'):
+        ConstraintCollocator(specialize_parameters='yes', **kw)

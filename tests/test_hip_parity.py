@@ -391,6 +391,62 @@ def test_specialised_kernels_follow_the_parameter_map():
     check('parameter changed again')
 
 
+#: known-parameter values of test_automatic_specialisation_gives_way_...
+AUTO_SPEC_VALUES = (None, 1.0625, 0.9375)
+
+
+def _auto_spec_problem(value):
+    kw = problems.build('one_legged_small')
+    key = sorted(kw['known_parameter_map'], key=str)[0]
+    if value is not None:
+        kw['known_parameter_map'][key] = \
+            float(kw['known_parameter_map'][key])*value
+    return kw, key
+
+
+def test_automatic_specialisation_gives_way_to_changing_parameters():
+    """``specialize_parameters=None`` on the muscle-driven leg: specialised
+    kernels without being asked (r06); a known parameter that changes is
+    followed by a rebuild once -- and by the generic module when it changes
+    again (a caller who sweeps a parameter must not pay a compile per
+    value).  Values are the reference-pinned generic collocator's every
+    time."""
+    import opty_amd
+    kw, key = _auto_spec_problem(None)
+    base = float(kw['known_parameter_map'][key])
+    col = opty_amd.ConstraintCollocator(**kw)
+    jac = col.generate_jacobian_function()
+    con = col.generate_constraint_function()
+    free = problems.make_free(col.num_free, seed=3, variable_duration=True)
+
+    def check(value, tag):
+        rkw, _ = _auto_spec_problem(value)
+        ref = opty_amd.ConstraintCollocator(specialize_parameters=False,
+                                            **rkw)
+        j_ref = np.array(ref.generate_jacobian_function()(free))
+        c_ref = ref.generate_constraint_function()(free)
+        ccap, jcap = gu.caps_for(j_ref, len(c_ref), ref.num_collocation_nodes
+                                 - 1, ref.num_eom, ref.num_block_columns)
+        gu.assert_close(np.array(jac(free)), j_ref, RTOL,
+                        what='auto-specialised jac ' + tag, cap=jcap)
+        gu.assert_close(con(free), c_ref, RTOL,
+                        what='auto-specialised con ' + tag, cap=ccap)
+        ref.hip.close()
+
+    check(None, 'initial')
+    assert col._auto_specialized is True and col._specialize
+    assert col._kernel_meta.get('auto_specialized')
+    col.known_parameter_map[key] = base*AUTO_SPEC_VALUES[1]
+    check(AUTO_SPEC_VALUES[1], 'first change')
+    assert col._specialize and col._respecializations == 1
+    col.known_parameter_map[key] = base*AUTO_SPEC_VALUES[2]
+    check(AUTO_SPEC_VALUES[2], 'second change')
+    assert not col._specialize and col._auto_specialized is None
+    col.known_parameter_map[key] = base
+    check(None, 'back')
+    assert not col._specialize          # ... for good
+
+
 def test_plan_flags_route_the_entry_points(tmp_path, monkeypatch):
     """What a launch plan measured decides which kernels an entry point
     launches: ``"jac_via_fused": true`` -> ``jacobian(free)`` comes from the
@@ -1169,6 +1225,11 @@ def prebuild_extras():
         factory, fkw = problems.CONFIGS[name]
         opty_amd.ConstraintCollocator(specialize_parameters=True,
                                       **factory(**fkw)).prebuild()
+    # the auto-specialised leg of test_automatic_specialisation_...: its
+    # specialised module for the first two parameter values
+    for value in AUTO_SPEC_VALUES[:2]:
+        opty_amd.ConstraintCollocator(**_auto_spec_problem(value)[0]
+                                      ).prebuild()
     kw = problems.mass_spring_damper(num_nodes=150)
     m = list(kw['known_parameter_map'])[0]
     for value in (None, 1.625, 0.75):
