@@ -96,8 +96,10 @@ class ConstraintCollocator(object):
         # built first; when its fused kernel spills at least
         # ``_AUTO_SPECIALIZE_SGPR_SPILLS`` scalar registers into vector lanes
         # -- the class that gains (the muscle-driven leg: 255-377 spilled
-        # SGPRs, -7 ... -13 %; the 24-link stand-ins -3 %; the biped, 58
-        # spilled, is no faster) -- and there are known parameters to print,
+        # SGPRs, -7 ... -13 %; not the biped, 58 spilled, which is no faster;
+        # not the 24-link stand-ins, store-bound blocks of 5 100 entries that
+        # would gain 3 % for a second compile of minutes) -- and there are
+        # known parameters to print,
         # the specialised module takes its place.  A caller whose known
         # parameters keep changing (two rebuilds) is moved back to the
         # generic module for good.  False: never.
@@ -712,6 +714,9 @@ class ConstraintCollocator(object):
                 self._pinned_build() is not None or base is None or \
                 base.fast_trig == 2 or opt_level is not None:
             return hsaco, meta
+        if isa_check.noted(hsaco, 'sibling_no_better'):
+            # (found out by an earlier build of the same module)
+            return hsaco, meta
         trial = copy.copy(base)
         trial.fast_trig = 2
         source, tmeta = self._emit(trial)
@@ -723,6 +728,8 @@ class ConstraintCollocator(object):
             logger.info('static ISA check: %s in %s; the uniform-sincos '
                         'sibling is no better (copies %s, spills %s): kept',
                         hits, os.path.basename(hsaco), thits, spills)
+            isa_check.note(hsaco, 'sibling_no_better',
+                           dict(copies=thits, spills=spills))
             return hsaco, meta
         logger.info('static ISA check: %s in %s: replaced by the uniform-'
                     'sincos sibling %s (clean)', hits,
@@ -736,6 +743,8 @@ class ConstraintCollocator(object):
     #: spilled scalar registers of the generic fused kernel from which the
     #: parameter-specialised module is used automatically
     _AUTO_SPECIALIZE_SGPR_SPILLS = 200
+    #: ... for blocks of at most this many entries per node
+    _AUTO_SPECIALIZE_MAX_BLOCK = 1024
 
     def _wants_auto_specialization(self, hsaco, opt_level):
         if self._specialize_mode is not None or self._specialize or \
@@ -745,6 +754,11 @@ class ConstraintCollocator(object):
                      not self._variable_duration):
             return False
         if self._pinned_build() is not None:
+            return False
+        if self._build_program().P > self._AUTO_SPECIALIZE_MAX_BLOCK:
+            # blocks this large are bound by their store stream, not by
+            # their instructions (the 24-link stand-ins: -3 % for a second
+            # compile of minutes)
             return False
         try:
             res = hb.cached_kernel_resources(hsaco)

@@ -150,3 +150,30 @@ def exec_copies(hsaco_path, names=('opty_con', 'opty_jac', 'opty_conjac')):
     except OSError:
         pass
     return {k: v for k, v in copies.items() if k in names}
+
+
+def noted(hsaco_path, key):
+    """A remark stored next to a code object's verdict (``note``), or None."""
+    try:
+        with open(hsaco_path + '.isa.json') as f:
+            return json.load(f).get('notes', {}).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def note(hsaco_path, key, value):
+    """Stores a remark next to a code object's verdict -- e.g. that its
+    uniform-sincos sibling was built and found no better, so that the next
+    build does not spend minutes of hipcc on finding out again."""
+    side = hsaco_path + '.isa.json'
+    try:
+        with open(side) as f:
+            got = json.load(f)
+        got.setdefault('notes', {})[key] = value
+        tmp = side + '.%d.tmp' % os.getpid()
+        with open(tmp, 'w') as f:
+            json.dump(got, f)
+        os.replace(tmp, side)
+    except (OSError, ValueError):
+        pass
+
