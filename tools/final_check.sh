@@ -4,7 +4,7 @@
 #   gpurun --timeout 2700 -- 'bash tools/final_check.sh <tag>'
 tag=${1:-final}
 mkdir -p gpurun_out/prof_$tag
-(time OPTY_CACHE_MANIFEST=$PWD/gpurun_out/${tag}_manifest.txt timeout 2400 python -m pytest tests -m gpu -q) > gpurun_out/${tag}_suite.log 2>&1
+(time OPTY_CACHE_MANIFEST=$PWD/gpurun_out/${tag}_manifest.txt timeout 2400 python -m pytest tests -m gpu -q --timeout 900) > gpurun_out/${tag}_suite.log 2>&1
 grep -a "passed\|failed" gpurun_out/${tag}_suite.log | tail -2
 cp gpurun_out/parity_stats.json gpurun_out/${tag}_parity_stats.json
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
