@@ -1352,7 +1352,10 @@ def test_refused_persistent_build_is_replaced_by_the_uniform_sincos_one(
     monkeypatch.setenv('OPTY_LAUNCH_PLANS', str(path))
     path.write_text(json.dumps({key: dict(options=dict(
         order='list', fused_order='list'))}))
+    # (the generic module: automatic parameter specialisation would print
+    # other kernels, which happen not to trigger the fault)
     col = opty_amd.ConstraintCollocator(jacobian_layout='csr',
+                                        specialize_parameters=False,
                                         tmp_dir=str(tmp_path/'cache'), **kw)
     hip = col.hip
     verdict = col._build_verdict
