@@ -37,6 +37,10 @@ def variants(base):
         o.chunk, o.groups, o.fused_groups, o.pad = 16, 4, 4, 0
         o.strips = o.fused_strips = CUT
         o.waves = 4
+        # (hardware dispatch, no LDS parking: what the publication stage is
+        # printed for; the full-size plan of the leg has a list schedule)
+        o.order = o.fused_order = None
+        o.park, o.share_rcp = 0, 0
         for k, v in kw.items():
             setattr(o, k, v)
         yield label, o
