@@ -1095,10 +1095,17 @@ static bool packing_pays(const opty_hip_problem *p) {
 
 double opty_hip_pack_ratio(void) { return pack_ratio(); }
 
+static double trace_now_ms() {
+    return std::chrono::duration<double, std::milli>(
+        std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
                                  double *jac, int32_t fresh) {
     if (!p) return fail("null handle");
     if (!free_ || !jac) return fail("null buffer");
+    static const bool trace_call = getenv("OPTY_HIP_TRACE") != nullptr;
+    const double t_call = trace_call ? trace_now_ms() : 0.0;
     if (int rc = use_device(p)) return rc;
     if (int rc = check_ready(p)) return rc;
     if (p->d.layout == OPTY_HIP_LAYOUT_SEGMENTED) {
@@ -1153,11 +1160,13 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
             return 0;
         };
     }
+    const double t_move = trace_call ? trace_now_ms() : 0.0;
     if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full, produce,
                                      W)) {
         p->static_valid = false;
         return rc;
     }
+    const double t_moved = trace_call ? trace_now_ms() : 0.0;
     if (p->d.nnz_inst > 0)
         HIP_TRY(hipMemcpyAsync(jac + P*ncn, p->d_jac + P*ncn,
                                p->d.nnz_inst*sizeof(double),
@@ -1166,6 +1175,11 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     if (p->copy_stream) HIP_TRY(hipStreamSynchronize(p->copy_stream));
     p->static_host = jac;
     p->static_valid = true;
+    if (trace_call)
+        fprintf(stderr, "opty_hip: jacobian call: set-up %.3f ms (buffers, "
+                "upload begin), pipeline %.3f ms, final synchronisation "
+                "%.3f ms\n", t_move - t_call, t_moved - t_move,
+                trace_now_ms() - t_moved);
     return 0;
 }
 

@@ -10,7 +10,7 @@ tests_host)
   timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q --timeout 300 -k "host or persistent or varying or known_maps or refused_persistent or wrong_high" > gpurun_out/gputest3b.log 2>&1; tail -5 gpurun_out/gputest3b.log;;
 trace)
   rm -f gpurun_out/host_trace3.txt
-  for v in "X=1" "OPTY_HIP_COPY_STREAMS=1" "OPTY_HIP_HOST_TAPER=0" "OPTY_HIP_COPY_STREAMS=1 OPTY_HIP_HOST_TAPER=0"; do echo "== $v" >> gpurun_out/host_trace3.txt; env $v timeout 300 python tools/host_path_trace.py 2>&1 >/dev/null | grep -E "^call 1[0-9]|chunks:" | tail -8 >> gpurun_out/host_trace3.txt; done
+  for v in "X=1" "OPTY_HIP_COPY_STREAMS=1" "OPTY_HIP_HOST_TAPER=0" "OPTY_HIP_COPY_STREAMS=1 OPTY_HIP_HOST_TAPER=0"; do echo "== $v" >> gpurun_out/host_trace3.txt; env $v timeout 300 python tools/host_path_trace.py 2>&1 >/dev/null | grep -E "^call 1[0-9]|chunks:|jacobian call" | tail -8 >> gpurun_out/host_trace3.txt; done
   cat gpurun_out/host_trace3.txt | cut -c1-200;;
 ab_rcp)
   rm -f gpurun_out/ab_share_rcp.txt

@@ -1,6 +1,8 @@
+"""GPU tool: a few jacobian(free) calls of config 3 through the host path with
+OPTY_HIP_TRACE=1 (where the time of a call goes: stderr)."""
 import os, sys, time
 os.environ['OPTY_HIP_TRACE']='1'
-sys.path.insert(0,'.')
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
 import numpy as np
 import opty_amd
 from examples import problems
