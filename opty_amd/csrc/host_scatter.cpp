@@ -652,7 +652,9 @@ private:
 // at the end of `free` go first.
 class FreeUploader {
 public:
-    int begin(opty_hip_problem *p, const double *free_, int W) {
+    // wb: W + 1 constraint-node bounds of the windows (null: equal parts)
+    int begin(opty_hip_problem *p, const double *free_, int W,
+              const long long *wb = nullptr) {
         p_ = p;
         W_ = W;
         N_ = p->d.N;
@@ -674,7 +676,8 @@ public:
             return rc;
         const long long ncn = p->ncon_nodes();
         bounds_.assign((size_t)W + 1, 0);
-        for (int w = 0; w < W; ++w) bounds_[(size_t)w + 1] = ncn*(w + 1)/W + 1;
+        for (int w = 0; w < W; ++w)
+            bounds_[(size_t)w + 1] = (wb ? wb[w + 1] : ncn*(w + 1)/W) + 1;
         // (the workers stay where the last scatter put them: restarting
         // them on another NUMA node costs more than a remote memcpy)
         pool_ = &ScatterPool::instance();
@@ -864,10 +867,58 @@ static int host_windows(const opty_hip_problem *p, size_t bytes,
     return (int)std::min<long long>(W, std::max<long long>(1, count/64));
 }
 
+// OPTY_HIP_HOST_SCHEDULE=2 (r06 experiment -> default if it pays): windows and
+// DMA chunks that are NOT equal parts.  A copy runs at 54.5 GB/s inside and
+// costs 11-18 us between two of them whatever its size, the first byte can
+// only leave once the first window is uploaded, evaluated and packed, and the
+// call ends one chunk's scatter after the last byte: so a tiny first window
+// (1 % of the nodes) with a chunk of its own, growing chunks (4 %, 15 %), 32 MB
+// copies through the bulk, and a tail that halves down to 2 MB.
+struct HostSchedule {
+    std::vector<long long> windows, chunks;     // node bounds, [0] = 0
+};
+
+static bool host_schedule(const opty_hip_problem *p, long long count, int V,
+                          HostSchedule *out) {
+    static const int mode = [] {
+        const char *v = getenv("OPTY_HIP_HOST_SCHEDULE");
+        return v ? atoi(v) : 1;
+    }();
+    const double bytes = (double)count*V*sizeof(double);
+    if (mode != 2 || bytes < (96u << 20) || count < 4096 ||
+        p->stream == (hipStream_t)OPTY_HIP_STREAM_LEGACY)
+        return false;
+    const long long per_mb = (long long)((1 << 20)/(V*sizeof(double))) + 1;
+    const double frac[] = {0.0, 0.01, 0.05, 0.20, 1.0};
+    out->windows.clear();
+    out->chunks.clear();
+    for (double f : frac) out->windows.push_back((long long)(count*f));
+    out->windows.back() = count;
+    for (int w = 0; w <= 3; ++w) out->chunks.push_back(out->windows[(size_t)w]);
+    // the bulk window: 32 MB copies, then 16, 8, 4, 2, 2
+    long long at = out->windows[3];
+    const long long tail_mb[] = {16, 8, 4, 2, 2};
+    long long tail_nodes = 0;
+    for (long long t : tail_mb) tail_nodes += t*per_mb;
+    const long long big = 32*per_mb;
+    while (count - at > tail_nodes + big/2) {
+        const long long left = count - at - tail_nodes;
+        at += left < big + big/2 ? left : big;
+        out->chunks.push_back(at);
+    }
+    for (long long t : tail_mb) {
+        at = std::min(count, at + t*per_mb);
+        if (at > out->chunks.back()) out->chunks.push_back(at);
+    }
+    if (out->chunks.back() != count) out->chunks.push_back(count);
+    return (int)out->chunks.size() - 1 <= ScatterPool::MAX_CHUNKS;
+}
+
 static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                                double *h_blocks, long long count, bool full,
                                const Producer &produce = Producer(),
-                               int windows = 0) {
+                               int windows = 0,
+                               const HostSchedule *plan = nullptr) {
     const int V = (int)p->var_entries.size();
     const long long P = p->P();
     if (count <= 0) return 0;
@@ -939,11 +990,17 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                         : host_windows(p, packed*sizeof(double), count);
         chunks = std::max(chunks, W);
     }
+    if (plan) {
+        W = (int)plan->windows.size() - 1;
+        chunks = (int)plan->chunks.size() - 1;
+    }
     // chunk c covers the nodes [bound(c), bound(c + 1)); kept in the handle:
     // the scatter workers read it (nobody does right now: quiesce() above)
     std::vector<long long> &bound = p->chunk_bounds;
     bound.clear();
-    {
+    if (plan) {
+        bound = plan->chunks;
+    } else {
         const bool tp = taper && chunks >= 4 &&
                         chunks + 2 <= ScatterPool::MAX_CHUNKS && produce;
         for (int c = 0; c <= chunks; ++c)
@@ -979,7 +1036,9 @@ static int move_blocks_to_host(opty_hip_problem *p, const double *d_blocks,
                                         : (W > 1 ? p->copy_stream : p->stream)};
     int next_chunk = 0;
     for (int w = 0; w < W; ++w) {
-        const long long wa = count*w/W, wb = count*(w + 1)/W;
+        const long long wa = plan ? plan->windows[(size_t)w] : count*w/W,
+                        wb = plan ? plan->windows[(size_t)w + 1]
+                                  : count*(w + 1)/W;
         if (produce)
             if (int rc = produce(wa, wb)) return rc;
         const long long part = (wb - wa)*V;
@@ -1131,6 +1190,8 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
                       p->static_host != jac || !packing_pays(p);
     Producer produce;
     FreeUploader up;
+    HostSchedule sched;
+    const HostSchedule *plan = nullptr;
     int W = 1, w = 0;
     if (full) {
         if (int rc = up.begin(p, free_, 1)) return rc;
@@ -1144,7 +1205,13 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
         // last window
         W = host_windows(p, p->var_entries.size()*(size_t)ncn*sizeof(double),
                          ncn);
-        if (int rc = up.begin(p, free_, W)) return rc;
+        if (host_schedule(p, ncn, (int)p->var_entries.size(), &sched)) {
+            plan = &sched;
+            W = (int)sched.windows.size() - 1;
+        }
+        if (int rc = up.begin(p, free_, W,
+                              plan ? plan->windows.data() : nullptr))
+            return rc;
         produce = [p, P, ncn, &up, &w](long long a, long long b) {
             if (int rc = up.window(w++, a == 0 ? a : a + 1, b + 1)) return rc;
             if (int rc = eval_device(p, OPTY_HIP_EVAL_JAC, p->d_free, nullptr,
@@ -1162,7 +1229,7 @@ int opty_hip_eval_jac_persistent(opty_hip_problem *p, const double *free_,
     }
     const double t_move = trace_call ? trace_now_ms() : 0.0;
     if (int rc = move_blocks_to_host(p, p->d_jac, jac, ncn, full, produce,
-                                     W)) {
+                                     W, plan)) {
         p->static_valid = false;
         return rc;
     }
