@@ -1130,3 +1130,21 @@ def test_automatic_parameter_specialisation_follows_the_scalar_spills():
     assert not small._specialize and small._auto_specialized is False
     with pytest.raises(ValueError, match='specialize_parameters'):
         ConstraintCollocator(specialize_parameters='yes', **kw)
+
+
+def test_integration_stub_descriptor_matches_the_abi():
+    """INTEGRATION.md shows the ctypes binding a maintainer of the reference
+    would add: its descriptor must be the header's, field for field (it went
+    stale between ABI versions 4 and 7 once)."""
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    blk = text[text.index('class OptyHipDesc'):
+               text.index('class OptyHipBinding')]
+    names = re.findall(r"'([a-zA-Z_]+)'", blk)
+    assert names == [n for n, _ in hb._Desc._fields_]
+    assert 'ABI version %d' % hb.ABI_VERSION in blk
+    header = open(os.path.join(REPO, 'include', 'opty_hip.h')).read()
+    struct = header[header.index('typedef struct opty_hip_desc {'):
+                    header.index('} opty_hip_desc;')]
+    fields = re.findall(r'^\s+(?:int64_t|int32_t|float)\s+([a-z_A-Z]+)',
+                        struct, re.M)
+    assert fields == names
