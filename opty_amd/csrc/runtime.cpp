@@ -308,14 +308,17 @@ bool routing_enabled() {
 }
 
 // Average duration (ms) of one issue of `fn` on the handle's stream: one
-// untimed issue, then the best of three timed batches (hipEvents; batches
-// long enough for the event resolution).
+// untimed issue, a short batch to size the others, then the best of three
+// timed batches of ~2 ms each (hipEvents).  Batches of a few launches are not
+// enough: the biped's opty_jac took 0.0667 ms in bursts of four and 0.0723 ms
+// sustained, next to a fused kernel at 0.0710 -- the decision flipped on the
+// length of the measurement (BENCH of r06's last day).
 template <typename Fn>
 int time_issue(opty_hip_problem *p, Fn fn, float *ms_out) {
     if (int rc = fn()) return rc;
     int n = 2;
     float best = 1e30f;
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < 4; ++round) {
         HIP_TRY(hipEventRecord(p->ev_cal0, p->stream));
         for (int i = 0; i < n; ++i)
             if (int rc = fn()) return rc;
@@ -323,12 +326,13 @@ int time_issue(opty_hip_problem *p, Fn fn, float *ms_out) {
         HIP_TRY(hipEventSynchronize(p->ev_cal1));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p->ev_cal0, p->ev_cal1));
-        if (ms/n < best) best = ms/n;
-        if (round == 0 && ms < 0.2f) {
+        if (round == 0) {
             const float per = ms/n > 1e-4f ? ms/n : 1e-4f;
-            const int want = (int)(0.25f/per) + 1;
-            n = want > 64 ? 64 : (want < n ? n : want);
+            const int want = (int)(2.0f/per) + 1;
+            n = want > 256 ? 256 : (want < 4 ? 4 : want);
+            continue;                   // sizing batch: not a measurement
         }
+        if (ms/n < best) best = ms/n;
     }
     *ms_out = best;
     return 0;
