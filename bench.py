@@ -331,10 +331,13 @@ def _other_config(name, dev, iters, out, torch, opty_amd, hb, problems):
     whats = [(hb.EVAL_CON, 'opty_con'), (hb.EVAL_JAC, 'opty_jac'),
              (hb.EVAL_FUSED, 'opty_conjac')]
     for what, label in whats:
-        hip.time_eval(what, free, con, jac, max(3, iters//4))
-        # (best of three batches: the entries are compared with each other
-        # to a per cent -- fused against the pair, opty_jac against fused)
-        res[label] = min(hip.time_eval(what, free, con, jac, iters)
+        ms0 = hip.time_eval(what, free, con, jac, max(3, iters//4))
+        # (best of three batches of at least ~4 ms each: the entries are
+        # compared with each other to a per cent -- fused against the pair,
+        # opty_jac against fused -- and twenty launches of a 30 us kernel do
+        # not resolve a per cent)
+        n = min(2000, max(iters, int(4.0/max(ms0, 1e-4)) + 1))
+        res[label] = min(hip.time_eval(what, free, con, jac, n)
                          for _ in range(3))
     route = _routing(hip)
     if not route['fused_pays'] and not hip.desc['routing'] & \
