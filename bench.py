@@ -509,10 +509,8 @@ def host_path(kw, dev_index, reps=15):
     # the PCIe link
     # The host path's own roofline: the bytes one jacobian(free) moves over
     # the link against what the link does on THIS box (page-locked
-    # hipMemcpy of 256 MB either way, best of 5).  `frac` = the download of
-    # the moved entries -- 92 % of the bytes -- at the measured device-to-
-    # host rate over the median call; the upload of `free` rides the other
-    # direction of the link.
+    # hipMemcpy of 256 MB either way, best of 5); `frac` and
+    # `frac_download_only` below.
     try:
         n = 32 << 20
         hbuf = hb.pinned_empty(n)
@@ -534,8 +532,16 @@ def host_path(kw, dev_index, reps=15):
         del hbuf
         pcie['link_GBps'] = rates
         pcie['d2h_GBps_achieved'] = pcie['d2h_bytes']/(out['jac']*1e-3)/1e9
-        pcie['frac'] = pcie['d2h_GBps_achieved']/rates['d2h']
-        pcie['frac_best_call'] = pcie['d2h_bytes']/(
+        # `frac` as VERDICT r05 item 3 defines it: the bytes a call moves,
+        # BOTH ways, over the median call, against the measured (one-way)
+        # link rate.  The link is full duplex and the upload rides in the
+        # shadow of the download, so the stricter reading is the download
+        # alone: `frac_download_only`
+        moved = pcie['h2d_bytes'] + pcie['d2h_bytes']
+        pcie['GBps_achieved'] = moved/(out['jac']*1e-3)/1e9
+        pcie['frac'] = pcie['GBps_achieved']/rates['d2h']
+        pcie['frac_download_only'] = pcie['d2h_GBps_achieved']/rates['d2h']
+        pcie['frac_download_only_best_call'] = pcie['d2h_bytes']/(
             out['jac_min']*1e-3)/1e9/rates['d2h']
         pcie['bound_ms'] = 1e3*pcie['d2h_bytes']/(rates['d2h']*1e9)
     except Exception as exc:             # noqa: secondary figure
