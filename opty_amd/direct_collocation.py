@@ -683,7 +683,13 @@ class ConstraintCollocator(object):
         it is clean -- no such copy, no vector spills --, BEFORE any GPU time
         is spent on either.  ``meta['isa_exec_copies']``
         carries the count of the build in use; the referee judges it like
-        any other build."""
+        any other build.
+
+        Before that: automatic parameter specialisation
+        (``specialize_parameters=None``) -- when the generic module's fused
+        kernel spills ``_AUTO_SPECIALIZE_SGPR_SPILLS`` scalar registers or
+        more, the module with the known parameters printed as literals is
+        built in its place (:meth:`_wants_auto_specialization`)."""
         import copy
         from . import isa_check
         hsaco, meta = self._build_spill_free(opt_level)
@@ -735,8 +741,8 @@ class ConstraintCollocator(object):
                     'sincos sibling %s (clean)', hits,
                     os.path.basename(hsaco), os.path.basename(twin))
         self._built_source, self._built_options = source, trial
-        keep = {k: meta[k] for k in ('banned_kernels', 'vector_spills')
-                if k in meta}
+        keep = {k: meta[k] for k in ('banned_kernels', 'vector_spills',
+                                     'auto_specialized') if k in meta}
         return twin, dict(tmeta, isa_exec_copies={}, isa_replaced=dict(hits),
                           **keep)
 
