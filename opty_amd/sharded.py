@@ -478,7 +478,17 @@ class ShardedCollocator(object):
         if params is not None:
             params = np.array(params, dtype=np.float64)
             self.known_parameters = params
-            if self._hip_mode and len(params):
+            if self._hip_mode and len(params) and col._specialize:
+                # parameter-specialised kernels (requested, or chosen by
+                # the collocator itself: specialize_parameters=None) carry
+                # the OLD values as literals: the values go into this rank's
+                # map and _sync_known prints, compiles and verifies the
+                # kernels for them
+                for sym, v in zip(col.known_parameters, params):
+                    col.known_parameter_map[sym] = float(v)
+                self._use_stream()
+                col._sync_known(col.hip, None)
+            elif self._hip_mode and len(params):
                 self._use_stream()
                 col.hip.set_known_parameters(params)
                 col._uploaded_parameters = params
