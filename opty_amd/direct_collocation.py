@@ -1703,6 +1703,7 @@ class ConstraintCollocator(object):
             hsaco, meta, self._build_verdict = self._verified_alternative(
                 hsaco, meta, err)
         hip = hb.HipProblem(self._descriptor(meta), hsaco)
+        hip.literals = self._known_scalars() if self._specialize else None
         self._install_tables(hip)
         self._kernel_meta = meta
         self._hip = hip
@@ -1719,6 +1720,7 @@ class ConstraintCollocator(object):
             hsaco, meta, self._build_verdict = self._verified_alternative(
                 hsaco, meta, err)
         hip.reload(self._descriptor(meta), hsaco)
+        hip.literals = self._known_scalars() if self._specialize else None
         self._kernel_meta = meta
         self._uploaded_parameters = self._uploaded_trajectories = None
         self._install_tables(hip)

@@ -767,12 +767,32 @@ class HipProblem(object):
     def synchronize(self):
         _check(self._lib.opty_hip_synchronize(self._h))
 
+    #: ``(known parameter values, fixed interval or None)`` that the loaded
+    #: kernels carry as LITERALS (parameter-specialised modules), else None
+    literals = None
+
+    def _refuse_other_literals(self, what, same):
+        if self.literals is not None and not same:
+            raise HipBackendError(
+                'the kernels of this handle carry the %s as literals '
+                '(parameter-specialised module): change the collocator\'s '
+                'known_parameter_map / node_time_interval and call '
+                'col.sync_known() -- it rebuilds them -- or build with '
+                'specialize_parameters=False' % what)
+
     def set_known_parameters(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64)
+        if self.literals is not None:
+            self._refuse_other_literals(
+                'known parameters', tuple(float(x) for x in v) ==
+                tuple(self.literals[0]))
         _check(self._lib.opty_hip_set_known_parameters(
             self._h, _ptr(v), len(v)))
 
     def set_interval(self, h):
+        if self.literals is not None and self.literals[1] is not None:
+            self._refuse_other_literals('node time interval',
+                                        float(h) == float(self.literals[1]))
         _check(self._lib.opty_hip_set_interval(self._h, float(h)))
 
     def set_known_trajectories(self, values):

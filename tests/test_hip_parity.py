@@ -436,6 +436,13 @@ def test_automatic_specialisation_gives_way_to_changing_parameters():
     check(None, 'initial')
     assert col._auto_specialized is True and col._specialize
     assert col._kernel_meta.get('auto_specialized')
+    # a handle whose kernels carry the values as literals refuses other
+    # values handed to it behind the collocator's back
+    from opty_amd import hip_backend as hb
+    vals = [float(col.known_parameter_map[p]) for p in col.known_parameters]
+    col.hip.set_known_parameters(vals)                  # the same: fine
+    with pytest.raises(hb.HipBackendError, match='literals'):
+        col.hip.set_known_parameters([v*1.5 for v in vals])
     col.known_parameter_map[key] = base*AUTO_SPEC_VALUES[1]
     check(AUTO_SPEC_VALUES[1], 'first change')
     assert col._specialize and col._respecializations == 1
