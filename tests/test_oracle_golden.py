@@ -13,9 +13,17 @@ from examples import problems
 from oracle.collocation_oracle import OracleCollocator, dense_from_coo
 
 
+_ORACLES = {}
+
+
 def _oracle(name):
-    return OracleCollocator(name=name.replace('_small', ''),
-                            **problems.build(name))
+    """One oracle per fixture and session: its symbolic Jacobian (SymPy
+    ``jacobian`` + ``cse``) is a minute and a half for the midpoint biped,
+    and two tests want it."""
+    if name not in _ORACLES:
+        _ORACLES[name] = OracleCollocator(name=name.replace('_small', ''),
+                                          **problems.build(name))
+    return _ORACLES[name]
 
 
 @pytest.mark.parametrize('name', gu.FULL_FAST)
@@ -182,7 +190,7 @@ def test_tolerance_floors_are_justified_by_the_oracle(name):
     import oracle_bounds
     meta, z = gu.load(name)
     kw = problems.build(name)
-    orc = OracleCollocator(name=name.replace('_small', ''), **kw)
+    orc = _oracle(name)
     orc.generate_jacobian_function()(z['free'])
     cmag, jmag = oracle_bounds.magnitudes(orc, z['free'])
     col = opty_amd.ConstraintCollocator(**kw)
